@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- macroblocks/s through the inter-frame encode hot path on MI355X.
+
+Workload (BASELINE.json metric: "macroblocks/sec (ME+DCT) at 1080p +-32px
+search"): a synthetic 1080p 30-frame GOP (1 I + 29 P frames, synth_gop), 16x16
+motion blocks -> +-32 px window on the reference's stride-5 grid, 8x8 DCT with
+the QF=50 tables, float64 coefficient planes.  One STEP = one pass of the hot
+path over the 29 P frames of the GOP: the motion-search kernel followed by the
+fused MC + residual + colour + DCT + quantise kernel, with every input already
+resident in HBM and every output left in HBM.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling --
+one long GOP with 29*N P frames, rank r owns P frames [29r, 29r+29).  The only
+exchanges of the path are in the timed step: an RCCL broadcast of the I frame
+from rank 0 and an all-gather of the motion vectors; coefficient planes stay on
+the GPU that produced them.  PyTorch is used for that plumbing only.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "vcs-h264_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy
+
+
+class _DevBytes:
+    """Zero-copy view of a libvcs_hip HBM buffer for torch (RCCL plumbing)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1",
+                                         "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(H, W, bs, ref, frames, budget_s=12.0):
+    """The CPU oracle (our C restatement, `kind: port`) on the same workload, all
+    host cores via OpenMP, on a bounded sample of the GOP's P frames."""
+    from oracle import oracle
+    # the GPU box grants 16 host cores per GPU; never oversubscribe past the affinity mask
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    oracle.set_threads(cores)
+    oracle.encode_p(frames[0][:64, :64].copy(), ref[:64, :64].copy(), bs)  # warm (build/load)
+    t0 = time.perf_counter()
+    done = 0
+    for k in range(len(frames)):
+        oracle.encode_p(frames[k], ref, bs)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    N = (H // bs) * (W // bs)
+    return {"value": round(done * N / dt / 1e3, 3), "unit": "macroblocks/ms", "cores": cores,
+            "kind": "port",
+            "sample": "%d of the GOP's P frames (%dx%d, ME %dx%d + 8x8 DCT), oracle/vcs_oracle.c "
+                      "with OpenMP, %.1f s" % (done, W, H, bs, bs, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--bs", type=int, default=16, help="motion block size (window = 2*bs)")
+    ap.add_argument("--frames", type=int, default=29, help="P frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import vcs_hip
+    from synth import synth_gop
+
+    H, W, bs, n = args.height, args.width, args.bs, args.frames
+    ctx = vcs_hip.Context(H, W, bs, 8, device=local_rank)
+    N, F = ctx.N, ctx.F
+    # this rank's slice of the (long) GOP; synthetic, deterministic
+    ref, frames = synth_gop(H, W, n, seed=1234, first=1 + rank * n)
+    ctx.gop_reserve(n)
+    ctx.gop_upload(0, frames)
+    if world > 1:
+        ptr, nb = ctx.dev_ptr(0)
+        t_ref = torch.as_tensor(_DevBytes(ptr, nb), device="cuda")
+        ptr, nb = ctx.dev_ptr(1)
+        t_mv = torch.as_tensor(_DevBytes(ptr, nb), device="cuda")
+        t_all = torch.empty(world * t_mv.numel(), dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            ctx.set_ref(ref)        # the I frame enters HBM on rank 0 only
+        ctx.ref_written()
+    else:
+        ctx.set_ref(ref)
+
+    def step():
+        if world > 1:
+            dist.broadcast(t_ref, src=0)             # I frame over xGMI
+            torch.cuda.current_stream().synchronize()
+        ctx.gop_encode(0, n)                         # ME kernel + fused tail kernel
+        if world > 1:
+            ctx.sync()
+            dist.all_gather_into_tensor(t_all, t_mv)  # motion-vector collection
+
+    def fence():
+        ctx.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ms, launches = ctx.timing()
+    ctx.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # parity guard on what was just timed: searched fraction + MV checksum
+    mv, ns = ctx.gop_get_mv(0, n)
+    searched = 1.0 - float(ns.sum()) / max(1, n * N)
+
+    if rank == 0:
+        units = world * n * N * args.steps              # macroblocks, whole job
+        value = units / dt / 1e3                        # macroblocks per millisecond
+        # algorithmic HBM bytes per macroblock: ME reads cur + ref and
+        # writes the vectors; the tail reads cur + ref + vectors, writes 3 f64 planes
+        per_mb = {vcs_hip.T_ME: (2 * F + 4 * N) / N, vcs_hip.T_ENC_TAIL: (10 * F + 4 * N) / N}
+        names = {vcs_hip.T_ME: "k_me", vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
+        dom = max(per_mb, key=lambda k: ms[k])
+        avg_ms = ms[dom] / max(1, int(launches[dom]))
+        achieved = per_mb[dom] * n * N / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "macroblocks/ms (16x16, ME+DCT encode) at 1080p +-32px search",
+            "value": round(value, 2), "unit": "macroblocks/ms",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (motion search) + f64 (DCT)", "data": "synthetic",
+            "config": {"workload": "configs[2]-shaped: synthetic %dx%d 30-frame GOP (1 I + %d P per "
+                                   "GPU), %dx%d motion blocks, +-%d px stride-%d grid search, 8x8 "
+                                   "DCT QF=50, float64 planes" % (W, H, n, bs, bs, 2 * bs,
+                                                                  round(bs / 3)),
+                       "frames_per_step_per_gpu": n, "macroblocks_per_frame": N,
+                       "searched_block_fraction": round(searched, 4),
+                       "parallelism": "P frames sharded over %d GPU(s)" % world},
+            "kernel_ms_per_step": {"me": round(ms[vcs_hip.T_ME] / args.steps, 4),
+                                   "enc_tail": round(ms[vcs_hip.T_ENC_TAIL] / args.steps, 4)},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(per_mb[dom] * n * N),
+                         "avg_launch_ms": round(avg_ms, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(H, W, bs, ref, frames)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

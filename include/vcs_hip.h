@@ -1,0 +1,169 @@
+/*
+ * vcs_hip.h -- C ABI of libvcs_hip.so: the MI355X (gfx950) implementation of
+ * the inter-frame encode hot path of miatang13/VCS-h264.
+ *
+ * The reference is pure Python and has no FFI layer; its boundary for this
+ * path is the class API used by InterframeCompression/main.py, encoder.py and
+ * decoder.py.  The drop-in modules in vcs-h264_amd/InterframeCompression/
+ * keep that class API and forward the work to the entry points below through
+ * ctypes.  Each entry point names the reference interface it replaces
+ * (file:line under /root/reference/InterframeCompression/).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative VCS_E* code; nothing
+ *     throws across the boundary; vcs_last_error() gives the message.
+ *   - frames are H x W x 3 uint8, BGR interleaved, C-contiguous (what
+ *     cv2.VideoCapture.read returns, main.py:35).  F = 3*H*W bytes.
+ *   - N = (H / me_bs) * (W / me_bs) motion blocks in raster order
+ *     (motion.py:74-98); motion vectors are N x [dx, dy] int16.
+ *   - coefficient planes are 3 planar H x W arrays [Y, Cr, Cb]
+ *     (DCTcompressor.py:73), element type per `coeff_mode`.
+ *   - host pointers are caller-owned; a context serialises its own calls
+ *     (one HIP stream per context); distinct contexts may be used from
+ *     distinct threads.  There is NO CPU fallback: without a usable GPU
+ *     vcs_ctx_create fails.
+ */
+#ifndef VCS_HIP_H
+#define VCS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCS_ABI_VERSION 1
+
+enum {
+    VCS_OK = 0,
+    VCS_E_ARG = -1,     /* bad argument / unsupported geometry              */
+    VCS_E_HIP = -2,     /* a HIP runtime call failed                        */
+    VCS_E_NOMEM = -3,   /* allocation failed                                */
+    VCS_E_STATE = -4,   /* call sequence error (e.g. no reference set)      */
+    VCS_E_RANGE = -5    /* a motion vector / block would read out of frame  */
+};
+
+enum {                  /* coefficient plane element type                   */
+    VCS_COEFF_F64 = 0,  /* float64, un-rounded: DCTcompressor.py:71 as is   */
+    VCS_COEFF_F32 = 1,  /* the same value rounded once to float32           */
+    VCS_COEFF_I16 = 2   /* np.round(value) as int16 (DCTCompression/dct.py:179) */
+};
+
+enum {                  /* indices into vcs_timing()                        */
+    VCS_T_ME = 0,       /* motion search kernel                             */
+    VCS_T_ENC_TAIL = 1, /* MC + residual + colour + DCT + quantise kernel   */
+    VCS_T_DEC = 2,      /* dequantise + IDCT + colour + MC-add kernel       */
+    VCS_T_AUX = 3,      /* stand-alone mc / residual / compress kernels     */
+    VCS_T_COUNT = 4
+};
+
+typedef struct vcs_ctx vcs_ctx;
+
+/* ---- library / device -------------------------------------------------- */
+int vcs_abi_version(void);
+int vcs_device_count(int *n);
+/* Message of the last failure on `ctx` (or, with ctx == NULL, of the last
+ * failed vcs_ctx_create / vcs_device_count on this thread).                 */
+const char *vcs_last_error(const vcs_ctx *ctx);
+
+/* ---- context ----------------------------------------------------------- */
+/* MotionProcessor.__init__ (motion.py:15-18) + DCTCompressor.__init__
+ * (DCTcompressor.py:43-46).  me_bs: motion block size (any >= 2);
+ * dct_bs must be 8 (the reference's Q tables are 8x8).  Defaults installed:
+ * win = 2*me_bs (motion.py:18), step = round(me_bs/3) (motion.py:132),
+ * sim_thresh = 2000 (motion.py:8), Q from QF = 50 (DCTcompressor.py:29-38),
+ * coeff_mode = VCS_COEFF_F64.                                               */
+int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **out);
+int vcs_ctx_destroy(vcs_ctx *ctx);
+
+/* Override the search / quantiser parameters.  win, step <= 0 and Q3x64 ==
+ * NULL keep the current value.  Q3x64: 3 x 8 x 8 float64, row-major, every
+ * entry finite and != 0 (the `Q` list of DCTcompressor.py:36-38).           */
+int vcs_set_params(vcs_ctx *ctx, int win, int step, int64_t sim_thresh,
+                   const double *Q3x64, int coeff_mode);
+/* Fills Q3x64 by the reference's QF rule (DCTcompressor.py:29-38).          */
+int vcs_make_q(double qf, double *Q3x64);
+/* The 8x8 DCT-II matrix of DCTcompressor.py:124-133, as the kernels use it. */
+int vcs_dct_matrix(double *D8x8);
+
+/* ---- single-frame entry points (host buffers) -------------------------- */
+/* Encoder._process_I_frame (encoder.py:41-43): the raw I frame becomes the
+ * reference of its GOP; copied to HBM once and kept resident.               */
+int vcs_set_ref(vcs_ctx *ctx, const uint8_t *ref_bgr);
+
+/* MotionProcessor.process_motion_prediction (motion.py:20-36, incl.
+ * _find_match :100-154 and _get_motion_vector :156-161).
+ * n_static (nullable): blocks that took the static early-out (:113).
+ * cost_out (nullable, N x uint64): winning cost per block (debug/parity).   */
+int vcs_me(vcs_ctx *ctx, const uint8_t *cur_bgr, int16_t *mv_out,
+           uint32_t *n_static, uint64_t *cost_out);
+
+/* MotionProcessor.reconstruct_from_motion_vectors (motion.py:42-69).
+ * coords: n x [x, y] int32, or NULL for the raster grid of motion.py:74-98
+ * (then n must be N).  Every source and destination block is bounds-checked
+ * on the host first (VCS_E_RANGE).  pred_out: F bytes, zero outside blocks. */
+int vcs_mc(vcs_ctx *ctx, const int16_t *mv, const int32_t *coords, int n,
+           uint8_t *pred_out);
+
+/* MotionProcessor.get_residuals (motion.py:38-40): a - b, uint8 wrap.
+ * sign = +1 gives a + b (decoder.py:57,60).  n bytes each.                  */
+int vcs_residual(vcs_ctx *ctx, const uint8_t *a, const uint8_t *b, int sign,
+                 size_t n, uint8_t *out);
+
+/* DCTCompressor.compress (DCTcompressor.py:49-74).  H and W must be
+ * multiples of 8 (cv2.resize at :52-53 is then the identity).               */
+int vcs_compress(vcs_ctx *ctx, const uint8_t *bgr, void *planes_out);
+/* DCTCompressor.decompress (DCTcompressor.py:76-93).                        */
+int vcs_decompress(vcs_ctx *ctx, const void *planes_in, uint8_t *bgr_out);
+
+/* Encoder._process_P_frame (encoder.py:49-70), fused: one upload, ME kernel,
+ * then one MC + residual + colour + DCT + quantise kernel.  planes_out /
+ * res_out nullable (res_out: the uint8 residual, i.e. with_DCT = False).    */
+int vcs_encode_p(vcs_ctx *ctx, const uint8_t *cur_bgr, int16_t *mv_out,
+                 void *planes_out, uint8_t *res_out, uint32_t *n_static);
+/* Decoder._reconstruct_P_frame + _fully_reconstruct (decoder.py:52-69).
+ * planes == NULL: motion compensation only (with_residuals = False).        */
+int vcs_decode_p(vcs_ctx *ctx, const int16_t *mv, const void *planes,
+                 uint8_t *bgr_out);
+
+/* ---- batched, HBM-resident GOP path ------------------------------------ */
+/* All P frames of a GOP depend only on the raw I frame (encoder.py:51-52), so
+ * a whole GOP is one launch chain.  Slots 0..n-1 hold P frames; outputs stay
+ * in HBM until downloaded.  vcs_gop_encode / vcs_gop_decode are asynchronous
+ * on the context's stream; vcs_sync() waits.                                */
+int vcs_gop_reserve(vcs_ctx *ctx, int n_slots, int with_decode);
+int vcs_gop_upload(vcs_ctx *ctx, int first_slot, int n, const uint8_t *frames);
+int vcs_gop_encode(vcs_ctx *ctx, int first_slot, int n);
+int vcs_gop_decode(vcs_ctx *ctx, int first_slot, int n);
+int vcs_gop_get_mv(vcs_ctx *ctx, int first_slot, int n, int16_t *mv_out,
+                   uint32_t *n_static_out /* n entries, nullable */);
+int vcs_gop_get_planes(vcs_ctx *ctx, int slot, void *planes_out);
+int vcs_gop_get_decoded(vcs_ctx *ctx, int slot, uint8_t *bgr_out);
+int vcs_sync(vcs_ctx *ctx);
+
+/* Device-side plumbing for the multi-GPU host layer (RCCL broadcast of the I
+ * frame, gather of motion vectors): raw HBM pointers of the context's
+ * resident buffers, valid until the context is destroyed / re-reserved.
+ * which: 0 = reference frame (F bytes), 1 = GOP motion vectors
+ * (n_slots*N*2 int16), 2 = GOP static counts (n_slots uint32).              */
+int vcs_dev_ptr(vcs_ctx *ctx, int which, void **ptr, size_t *bytes);
+/* Marks the resident reference as valid after it was written through
+ * vcs_dev_ptr(ctx, 0, ...) by a collective.                                 */
+int vcs_ref_written(vcs_ctx *ctx);
+
+/* ---- measurement ------------------------------------------------------- */
+/* With timing on, every kernel launch is bracketed by HIP events on the
+ * context's stream; vcs_timing() synchronises and returns, per VCS_T_* slot,
+ * the accumulated kernel milliseconds and launch counts since the last
+ * vcs_timing_reset().                                                       */
+int vcs_timing_enable(vcs_ctx *ctx, int on);
+int vcs_timing_reset(vcs_ctx *ctx);
+int vcs_timing(vcs_ctx *ctx, double *ms_out, uint64_t *launches_out, int n);
+/* Bytes/s of a device-to-device copy of `bytes` (the practical HBM roof).   */
+int vcs_measure_copy_bw(vcs_ctx *ctx, size_t bytes, int iters, double *gbps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCS_HIP_H */

@@ -1,0 +1,368 @@
+"""Parity of the HIP path (through the C ABI / the drop-in classes) against
+(a) the golden vectors captured from the reference and (b) the CPU oracle on
+seeded inputs.  Everything is bit-exact: motion vectors, MC image, residual,
+float64 coefficient planes, decoded pixels.  Needs an MI355X: -m gpu."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def vh():
+    import vcs_hip
+    vcs_hip.load()
+    assert vcs_hip.device_count() >= 1, "no GPU visible to libvcs_hip"
+    return vcs_hip
+
+
+def ctx_for(vh, frame, bs):
+    H, W = frame.shape[:2]
+    return vh.Context(H, W, bs)
+
+
+# ---------------------------------------------------------------- golden ----
+@pytest.mark.parametrize("bs", [4, 8, 16])
+def test_golden_me_small(vh, bs):
+    g = load_golden("me_small.npz")
+    ref, cur = g["ref"], g["cur"]
+    with ctx_for(vh, ref, bs) as c:
+        c.set_ref(ref)
+        mv, ns = c.me(cur)
+        assert np.array_equal(mv, g["mv_%d" % bs])
+        pred = c.mc(mv)
+        assert np.array_equal(pred, g["mc_%d" % bs])
+        assert np.array_equal(c.residual(cur, pred), g["res_%d" % bs])
+        _, _, res, _ = c.encode_p(cur, want_planes=False, want_res=True)
+        assert np.array_equal(res, g["res_%d" % bs])
+
+
+def test_golden_me_edges(vh, oracle):
+    g = load_golden("me_edges.npz")
+    names = [str(n) for n in g["names"]]
+    for k, name in enumerate(names):
+        ref, cur, bs = g["c%d_ref" % k], g["c%d_cur" % k], int(g["c%d_bs" % k])
+        with ctx_for(vh, ref, bs) as c:
+            c.set_ref(ref)
+            mv, ns, cost = c.me(cur, want_cost=True)
+            assert np.array_equal(mv, g["c%d_mv" % k]), name
+            omv, ons, ocost = oracle.me(cur, ref, bs, want_cost=True)
+            assert ns == ons, name
+            assert np.array_equal(cost, ocost), name
+            pred = c.mc(mv)
+            assert np.array_equal(pred, g["c%d_mc" % k]), name
+            assert np.array_equal(c.residual(cur, pred), g["c%d_res" % k]), name
+
+
+@pytest.mark.parametrize("bs", [16, 8])
+def test_golden_me_1080p(vh, bs):
+    from synth import synth_v1
+    g = load_golden("me_1080p.npz")
+    ref, cur = synth_v1(1080, 1920, seed=1234)
+    if sha(ref) != str(g["ref_sha"]) or sha(cur) != str(g["cur_sha"]):
+        pytest.skip("synthetic input drifted (numpy RNG differs from the fixture's)")
+    with ctx_for(vh, ref, bs) as c:
+        c.set_ref(ref)
+        mv, planes, res, ns = c.encode_p(cur, want_planes=False, want_res=True)
+        assert np.array_equal(mv, g["mv_%d" % bs])
+        assert sha(res) == str(g["res_sha_%d" % bs])
+        assert sha(c.mc(mv)) == str(g["mc_sha_%d" % bs])
+
+
+@pytest.mark.parametrize("qf", [10, 50, 99])
+def test_golden_dct_small(vh, qf):
+    g = load_golden("dct_small.npz")
+    img, Q = g["img"], g["Q_q%d" % qf]
+    assert np.array_equal(vh.make_q(float(qf)), Q)
+    assert np.array_equal(vh.dct_matrix(), g["dctmat"])
+    with ctx_for(vh, img, 8) as c:
+        c.set_params(Q=Q)
+        planes = c.compress(img)
+        assert planes.dtype == np.float64
+        assert np.array_equal(planes, g["planes_q%d" % qf])
+        assert np.array_equal(c.decompress(g["planes_q%d" % qf]), g["dec_q%d" % qf])
+
+
+def test_golden_codec_dropin(vh, capsys):
+    """The reference's own call sequence (main.py:29-50) on the drop-in classes."""
+    import encoder as E
+    import decoder as D
+    g = load_golden("codec_small.npz")
+    frames = g["frames"]
+    H, W = frames.shape[1:3]
+    for with_dct, tag in ((True, "dct"), (False, "raw")):
+        enc = E.Encoder(pattern=["I", "P", "P"], shape=[H, W], block_size=8, with_DCT=with_dct)
+        for n in range(len(frames)):
+            enc.encode_frame(frames[n], n)
+        assert [f.t for f in enc.encoded_frames] == ["I", "P", "P", "I", "P"]
+        assert enc.ref_frames[0] is frames[0] or np.shares_memory(enc.ref_frames[0], frames[0])
+        sink = []
+        dec = D.Decoder(encoded_frames=enc.encoded_frames, fps=25.0, shape=[H, W],
+                        ref_frames=enc.ref_frames, block_size=8, with_DCT=with_dct,
+                        sink=sink.append)
+        for n, fr in enumerate(enc.encoded_frames):
+            assert fr.i == n and fr.ref_i == int(g["%s_refi_%d" % (tag, n)])
+            if fr.t != "P":
+                continue
+            assert isinstance(fr.mv, list) and isinstance(fr.mv[0][0], int)
+            assert np.array_equal(np.array(fr.mv), g["%s_mv_%d" % (tag, n)])
+            if with_dct:
+                assert isinstance(fr.r, list) and len(fr.r) == 3
+                assert np.array_equal(np.stack(fr.r), g["dct_r_%d" % n])
+            else:
+                assert np.array_equal(fr.r, g["raw_r_%d" % n])
+            assert np.array_equal(dec._reconstruct_P_frame(fr, True), g["%s_full_%d" % (tag, n)])
+            assert np.array_equal(dec._reconstruct_P_frame(fr, False),
+                                  g["%s_mconly_%d" % (tag, n)])
+        dec.reconstruct_video(with_residuals=True)
+        assert len(sink) == 5
+        assert np.array_equal(sink[4], g["%s_full_4" % tag])
+    capsys.readouterr()
+
+
+def test_golden_motion_dropin_classes(vh, capsys):
+    """MotionProcessor / DCTCompressor used stand-alone, as encoder.py does."""
+    import motion as M
+    import DCTcompressor as C
+    g = load_golden("me_small.npz")
+    ref, cur = g["ref"], g["cur"]
+    mp = M.MotionProcessor(16, [ref.shape[0], ref.shape[1]])
+    mvs, coords = mp.process_motion_prediction(cur, ref)
+    assert np.array_equal(np.array(mvs), g["mv_16"])
+    assert np.array_equal(np.array(coords), g["coords_16"])
+    img = mp.reconstruct_from_motion_vectors(mvs, ref, coords)
+    assert np.array_equal(img, g["mc_16"])
+    res = mp.get_residuals(input_frame=cur, reconstructed=img)
+    assert np.array_equal(res, g["res_16"])
+    # a permuted coords list takes the explicit-coords kernel path
+    perm = np.random.default_rng(0).permutation(len(mvs))
+    img2 = mp.reconstruct_from_motion_vectors([mvs[i] for i in perm], ref,
+                                              [coords[i] for i in perm])
+    assert np.array_equal(img2, g["mc_16"])
+    d = load_golden("dct_small.npz")
+    c = C.DCTCompressor(8)
+    out = c.compress(d["img"])
+    assert np.array_equal(np.stack(out), d["planes_q50"])
+    assert np.array_equal(c.decompress(compressed=out, imshape=d["img"].shape), d["dec_q50"])
+    c.Q = list(d["Q_q10"])  # instances expose .Q; substituting tables is the "q sweep"
+    assert np.array_equal(np.stack(c.compress(d["img"])), d["planes_q10"])
+    with pytest.raises(ValueError):
+        C.DCTCompressor(16).compress(d["img"])
+    capsys.readouterr()
+
+
+@pytest.mark.parametrize("nm", ["jump", "corgi"])
+def test_golden_real_small(vh, nm):
+    g = load_golden("real_small.npz")
+    ref, cur = g[nm + "_ref"], g[nm + "_cur"]
+    for bs in (8, 16):
+        with ctx_for(vh, ref, bs) as c:
+            c.set_ref(ref)
+            mv, planes, res, ns = c.encode_p(cur, want_planes=(bs == 16), want_res=True)
+            assert np.array_equal(mv, g["%s_mv_%d" % (nm, bs)])
+            assert sha(res) == str(g["%s_res_sha_%d" % (nm, bs)])
+            if bs == 16:
+                assert sha(planes) == str(g[nm + "_planes16_sha"])
+                assert np.array_equal(c.decode_p(mv, planes), g[nm + "_full16"])
+
+
+# ---------------------------------------------------------------- oracle ----
+@pytest.mark.parametrize("H,W,bs", [
+    (64, 64, 16), (72, 88, 8), (50, 70, 8), (70, 90, 16), (30, 26, 4), (33, 47, 5),
+    (40, 52, 6), (60, 72, 12), (96, 160, 32), (17, 23, 2), (41, 39, 3), (128, 96, 16),
+    (21, 64, 7), (200, 328, 16), (136, 240, 8)])
+def test_me_vs_oracle_shapes(vh, oracle, H, W, bs):
+    rng = np.random.default_rng(H * 1000 + W + bs)
+    for trial in range(3):
+        ref = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        if trial == 0:
+            cur = np.roll(ref, (rng.integers(-6, 7), rng.integers(-6, 7)), axis=(0, 1))
+        elif trial == 1:
+            cur = ref.copy()
+            m = rng.random((H, W, 1)) < 0.3
+            cur = np.where(m, rng.integers(0, 256, (H, W, 3), dtype=np.uint8), cur)
+        else:
+            cur = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        with vh.Context(H, W, bs) as c:
+            c.set_ref(ref)
+            mv, ns, cost = c.me(cur, want_cost=True)
+            omv, ons, ocost = oracle.me(cur, ref, bs, want_cost=True)
+            assert np.array_equal(mv, omv)
+            assert ns == ons
+            assert np.array_equal(cost, ocost)
+            assert np.array_equal(c.mc(mv), oracle.mc(ref, omv, bs))
+
+
+def test_me_params_vs_oracle(vh, oracle):
+    """Non-default window / stride / threshold (the `step=1` dense search of
+    SURVEY 8f N4 included): oracle is the only checker here."""
+    from synth import synth_v1
+    ref, cur = synth_v1(96, 128, seed=5)
+    for bs, win, step, thr in [(16, 32, 1, 2000), (16, 16, 2, 0), (8, 16, 1, 500),
+                               (16, 40, 5, 10**12), (4, 8, 1, 100), (8, 24, 4, 2000)]:
+        with vh.Context(96, 128, bs) as c:
+            c.set_params(win=win, step=step, sim_thresh=thr)
+            c.set_ref(ref)
+            mv, ns, cost = c.me(cur, want_cost=True)
+            omv, ons, ocost = oracle.me(cur, ref, bs, win=win, step=step,
+                                        thresh=min(thr, 2**32 - 1), want_cost=True)
+            assert np.array_equal(mv, omv), (bs, win, step, thr)
+            assert ns == ons and np.array_equal(cost, ocost)
+    with vh.Context(96, 128, 8) as c:  # negative threshold: nothing can be static
+        c.set_params(sim_thresh=-1)
+        c.set_ref(ref)
+        mv, ns = c.me(ref)
+        assert ns == 0
+
+
+@pytest.mark.parametrize("me_bs", [8, 16])
+def test_encode_decode_vs_oracle(vh, oracle, me_bs):
+    from synth import synth_v1
+    ref, cur = synth_v1(136, 200, seed=77)
+    for qf in (10.0, 50.0, 99.0):
+        Q = oracle.make_q(qf)
+        with vh.Context(136, 200, me_bs) as c:
+            c.set_params(Q=Q)
+            c.set_ref(ref)
+            mv, planes, res, ns = c.encode_p(cur, want_planes=True, want_res=True)
+            omv, oplanes, ons, ores = oracle.encode_p(cur, ref, me_bs, Q=Q, want_res=True)
+            assert np.array_equal(mv, omv) and ns == ons
+            assert np.array_equal(res, ores)
+            assert np.array_equal(planes, oplanes)
+            assert np.array_equal(c.decode_p(mv, planes), oracle.decode_p(omv, oplanes, ref, me_bs, Q=Q))
+            assert np.array_equal(c.decode_p(mv, None), oracle.mc(ref, omv, me_bs))
+            assert np.array_equal(c.compress(cur), oracle.compress(cur, Q))
+            assert np.array_equal(c.decompress(oplanes), oracle.decompress(oplanes, Q))
+
+
+def test_dct_extremes_vs_oracle(vh, oracle):
+    rng = np.random.default_rng(3)
+    H, W = 64, 72
+    imgs = [np.zeros((H, W, 3), np.uint8), np.full((H, W, 3), 255, np.uint8),
+            rng.integers(0, 256, (H, W, 3), dtype=np.uint8),
+            (rng.integers(0, 2, (H, W, 3)) * 255).astype(np.uint8)]
+    with vh.Context(H, W, 8) as c:
+        for img in imgs:
+            planes = c.compress(img)
+            assert np.array_equal(planes, oracle.compress(img))
+            assert np.array_equal(c.decompress(planes), oracle.decompress(planes))
+        # arbitrary (not DCT-produced) planes exercise the truncating store + wraps
+        wild = rng.normal(0, 40, (3, H, W))
+        assert np.array_equal(c.decompress(wild), oracle.decompress(wild))
+
+
+def test_coeff_modes_vs_oracle(vh, oracle):
+    from synth import synth_v1
+    ref, cur = synth_v1(64, 96, seed=11)
+    omv, oplanes, ons = oracle.encode_p(cur, ref, 16)
+    with vh.Context(64, 96, 16) as c:
+        c.set_ref(ref)
+        c.set_params(coeff_mode=vh.VCS_COEFF_F32)
+        mv, planes, _, _ = c.encode_p(cur)
+        assert planes.dtype == np.float32
+        assert np.array_equal(planes, oplanes.astype(np.float32))
+        c.set_params(coeff_mode=vh.VCS_COEFF_I16)
+        mv, planes, _, _ = c.encode_p(cur)
+        assert planes.dtype == np.int16
+        assert np.array_equal(planes, oracle.round_i16(oplanes))
+        # rounded levels decode like float64 planes holding the same integers
+        assert np.array_equal(c.decode_p(mv, planes),
+                              oracle.decode_p(omv, planes.astype(np.float64), ref, 16))
+
+
+# ------------------------------------------------------------- GOP / 1080p ----
+def test_gop_1080p_vs_oracle(vh, oracle):
+    """BASELINE workload shape: 1080p, 16x16 motion blocks (+-32), 8x8 DCT."""
+    from synth import synth_gop
+    H, W, n = 1080, 1920, 4
+    ref, frames = synth_gop(H, W, n, seed=1234)
+    with vh.Context(H, W, 16) as c:
+        c.set_ref(ref)
+        c.gop_reserve(n, with_decode=True)
+        c.gop_upload(0, frames)
+        c.gop_encode(0, n)
+        c.gop_decode(0, n)
+        mv, ns = c.gop_get_mv(0, n)
+        for k in range(n):
+            omv, ons = oracle.me(frames[k], ref, 16)
+            assert np.array_equal(mv[k], omv), k
+            assert ns[k] == ons
+        # property at full size: every vector lies on the reference's stride-5 grid
+        assert ((mv[..., 0] + 32) % 5 == 0)[:, 2 * 120 + 2].all()
+        for k in (0, n - 1):
+            _, oplanes, _ = oracle.encode_p(frames[k], ref, 16)
+            planes = c.gop_get_planes(k)
+            assert np.array_equal(planes, oplanes), k
+            dec = c.gop_get_decoded(k)
+            assert np.array_equal(dec, oracle.decode_p(mv[k], oplanes, ref, 16))
+            # round trip: the un-rounded quantiser makes the codec lossless up to
+            # the +-1 truncation noise in YCrCb and the colour conversion itself
+            err = np.abs(dec.astype(np.int16) - frames[k].astype(np.int16))
+            err = np.minimum(err, 256 - err)
+            assert err.max() <= 6 and err.mean() < 1.5
+
+
+def test_gop_matches_single_frame_calls(vh):
+    from synth import synth_gop
+    H, W, n = 144, 176, 5
+    ref, frames = synth_gop(H, W, n, seed=3)
+    with vh.Context(H, W, 8) as c:
+        c.set_ref(ref)
+        c.gop_reserve(n)
+        c.gop_upload(0, frames[:2])
+        c.gop_upload(2, frames[2:])
+        c.gop_encode(0, 3)
+        c.gop_encode(3, 2)
+        mv, ns = c.gop_get_mv(0, n)
+        for k in range(n):
+            smv, splanes, _, sns = c.encode_p(frames[k])
+            assert np.array_equal(mv[k], smv) and ns[k] == sns
+            assert np.array_equal(c.gop_get_planes(k), splanes)
+
+
+def test_residual_roundtrip_property_1080p(vh):
+    """pred + (cur - pred) == cur with uint8 wrap, at full size."""
+    from synth import synth_v1
+    ref, cur = synth_v1(1080, 1920, seed=9)
+    with vh.Context(1080, 1920, 16) as c:
+        c.set_ref(ref)
+        mv, _, res, _ = c.encode_p(cur, want_planes=False, want_res=True)
+        pred = c.mc(mv)
+        assert np.array_equal(c.residual(pred, res, +1), cur)
+        assert (pred[1072:] == 0).all()  # 1080 % 16 rows are never covered (motion.py:83-87)
+        assert np.array_equal(res[1072:], cur[1072:])
+
+
+# ------------------------------------------------------------- errors ----
+def test_error_paths(vh):
+    with pytest.raises(vh.VcsError):
+        vh.Context(64, 64, 1)
+    with pytest.raises(vh.VcsError):
+        vh.Context(64, 64, 8, dct_bs=4)
+    with vh.Context(64, 64, 16) as c:
+        with pytest.raises(vh.VcsError) as e:
+            c.me(np.zeros((64, 64, 3), np.uint8))
+        assert e.value.code == -4  # VCS_E_STATE: no reference
+        c.set_ref(np.zeros((64, 64, 3), np.uint8))
+        bad = np.zeros((16, 2), np.int16)
+        bad[5] = (100, 0)
+        with pytest.raises(vh.VcsError) as e:
+            c.mc(bad)
+        assert e.value.code == -5  # VCS_E_RANGE
+        with pytest.raises(vh.VcsError):
+            c.decode_p(bad, None)
+        with pytest.raises(ValueError):
+            c.me(np.zeros((32, 64, 3), np.uint8))
+        with pytest.raises(vh.VcsError):
+            c.set_params(win=500)
+    with vh.Context(50, 70, 8) as c:  # DCT path refuses non-multiples of 8
+        with pytest.raises(vh.VcsError):
+            c.compress(np.zeros((50, 70, 3), np.uint8))

@@ -1,0 +1,79 @@
+"""Encoder -- drop-in for the reference's InterframeCompression/encoder.py
+(:9-70): same constructor, `encode_frame`, `encoded_frames`, `ref_frames`.
+
+P frames go through the fused HIP path (one upload, motion search kernel, one
+MC + residual + colour + DCT + quantise kernel, one download) instead of four
+separate host round trips; the stored Frame is identical to the reference's.
+
+Extension (keyword-only): `dct_block_size` -- the reference hands ONE
+block_size to both MotionProcessor and DCTCompressor (encoder.py:16-18), so
+with_DCT only works at 8; pass dct_block_size=8 to compose e.g. 16x16 motion
+blocks with the 8x8 DCT (the BASELINE workload).
+"""
+import math
+
+import numpy as np
+
+from DCTcompressor import DCTCompressor
+from frame import Frame
+from motion import MotionProcessor, _as_frame
+from _runtime import ensure_q, ensure_ref
+
+
+class Encoder:
+
+    def __init__(self, pattern, shape, block_size, with_DCT, *, dct_block_size=None, device=0):
+        self.ref_frames = []
+        self.encoded_frames = []
+        self.pattern = pattern
+        self.ENCODING_PATTERN_LENGTH = len(pattern)
+        self.MotionProcessor = MotionProcessor(block_size=block_size, shape=shape, device=device)
+        self.DCTCompressor = DCTCompressor(
+            block_size=block_size if dct_block_size is None else dct_block_size, device=device)
+        self.with_DCT = with_DCT
+
+    def encode_frame(self, input_frame, frame_num):
+        print("Encoding new frame of index", frame_num)
+        if frame_num % self.ENCODING_PATTERN_LENGTH == 0:  # encoder.py:25
+            encoded_frame = self._process_I_frame(input_frame, frame_num)
+        else:
+            encoded_frame = self._process_P_frame(input_frame, frame_num)
+        print("Encoded frame of type", encoded_frame.t)
+        self.encoded_frames.append(encoded_frame)
+        return
+
+    #################################################################
+    # PRIVATE METHODS
+
+    def _process_I_frame(self, input_frame, frame_num):
+        self.ref_frames.append(input_frame)  # aliases the caller's array (encoder.py:42)
+        return Frame("I", None, None, None, frame_num, frame_num % self.ENCODING_PATTERN_LENGTH)
+
+    def _process_B_frame(self, input, frame_num):
+        return  # not implemented upstream either (encoder.py:45-47)
+
+    def _process_P_frame(self, input, frame_num):
+        print("Processing P frame")
+        ref_idx = math.floor(frame_num / self.ENCODING_PATTERN_LENGTH)  # encoder.py:51
+        ref = self.ref_frames[ref_idx]
+        mp, dc = self.MotionProcessor, self.DCTCompressor
+        cur = _as_frame(input, mp.shape, "input_frame")
+        if self.with_DCT:
+            dc._check(mp.shape[0], mp.shape[1])
+        ctx = mp._ctx()
+        ensure_ref(ctx, _as_frame(ref, mp.shape, "ref_frame"))
+        if self.with_DCT:
+            ensure_q(ctx, dc.Q, dc.coeff_mode)
+        mv, planes, res, n_static = ctx.encode_p(cur, want_planes=bool(self.with_DCT),
+                                                 want_res=not self.with_DCT)
+        mp.last_static_blocks = n_static
+        print("Finished processing motion. Got motion vectors.")
+        num_static = int(np.count_nonzero((mv == 0).all(axis=1)))
+        print("There are", num_static, "static blocks out of", len(mv), "blocks")
+        if self.with_DCT:
+            print("begin compression")
+            r = [planes[0], planes[1], planes[2]]
+        else:
+            r = res
+        return Frame("P", motion_vectors=mv.astype(np.int64).tolist(), residuals=r,
+                     block_coords=mp._block_coords().tolist(), index=frame_num, ref_idx=ref_idx)

@@ -1,0 +1,259 @@
+// dct_kernels.hpp -- 8x8 DCT / quantise and dequantise / IDCT on gfx950
+// (DCTcompressor.py:49-93), fused with motion compensation and the residual
+// (motion.py:38-69, encoder.py:58-66, decoder.py:52-69).
+//
+// Arithmetic contract (bit-exact with oracle/vcs_oracle.c, which is pinned to
+// the reference's outputs): every 8x8 matrix product is a k-ascending chain
+// of fused multiply-adds in float64 starting from +0.0; the quantiser is an
+// IEEE division (np.true_divide, :71), the dequantiser an IEEE product (:86).
+// This translation unit is compiled with -ffp-contract=off so that only the
+// explicit fma() calls fuse.
+//
+// Mapping: one wavefront owns 8 horizontally adjacent tiles (64 px x 8 rows).
+// Stage 1, lane = (tile t, column j): the lane holds column j of its tile for
+// the three channels in registers and multiplies by the wave-uniform DCT
+// matrix (scalar loads).  The 8x8 intermediate goes through LDS once to turn
+// columns into rows; stage 2, lane = (tile t, row i), produces 8 horizontally
+// adjacent outputs per lane, i.e. 64 contiguous bytes of a float64 plane.
+#pragma once
+#include "vcs_common.hpp"
+
+namespace vcs {
+
+constexpr int kTilePad = 72;  // doubles per tile in the LDS transpose buffer
+
+// coefficient store / load for the three coefficient modes (vcs_hip.h)
+template <int CM> struct CoeffT;
+template <> struct CoeffT<0> { using type = double; };
+template <> struct CoeffT<1> { using type = float; };
+template <> struct CoeffT<2> { using type = int16_t; };
+
+template <int CM>
+__device__ __forceinline__ typename CoeffT<CM>::type coeff_pack(double v) {
+    if constexpr (CM == 0) return v;
+    else if constexpr (CM == 1) return (float)v;
+    else return (int16_t)(int)__builtin_rint(v);  // np.round: half to even
+}
+
+// Predicted (motion-compensated) pixel for frame position (y, x), or 0 where
+// no full motion block covers it (motion.py:45-46, :83-87).
+__device__ __forceinline__ void pred_px(const uint8_t *__restrict__ ref,
+                                        const int16_t *__restrict__ mv, const Geom &g,
+                                        int y, int x, int &b0, int &b1, int &b2) {
+    b0 = b1 = b2 = 0;
+    if (y < g.nby * g.bs && x < g.nbx * g.bs) {
+        int blk = (y / g.bs) * g.nbx + (x / g.bs);
+        int dx = mv[2 * blk], dy = mv[2 * blk + 1];
+        const uint8_t *p = ref + (size_t)(y + dy) * g.pitch + (size_t)(3 * (x + dx));
+        b0 = p[0];
+        b1 = p[1];
+        b2 = p[2];
+    }
+}
+
+// --------------------------------------------------------------------------
+// k_fdct: MODE 0 = DCTCompressor.compress on a BGR image (DCTcompressor.py:
+//         49-74); MODE 1 = the encoder tail for a P frame: motion
+//         compensation + wrap-around residual + compress, fused
+//         (encoder.py:58-66).  grid = (tile groups per frame, frames).
+// DQ: D[64] followed by Q[3][64], float64, in HBM (context-owned).
+// --------------------------------------------------------------------------
+template <int MODE, int CM>
+__global__ __launch_bounds__(64) void k_fdct(
+    const uint8_t *__restrict__ imgs, size_t img_stride, const uint8_t *__restrict__ ref,
+    const int16_t *__restrict__ mvs, Geom g, const double *__restrict__ DQ,
+    typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride) {
+    __shared__ double s_t[8 * kTilePad];
+    const int lane = threadIdx.x;
+    const int t = lane >> 3, j = lane & 7;
+    const int groups_x = (g.W + 63) >> 6;
+    const int ty = blockIdx.x / groups_x, gx = blockIdx.x - ty * groups_x;
+    const int f = blockIdx.y;
+    const int x = gx * 64 + lane;  // stage-1 pixel column of this lane
+    const bool live = x < g.W;     // W is a multiple of 8: tiles are whole
+    const uint8_t *__restrict__ img = imgs + (size_t)f * img_stride;
+    const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
+    const double *__restrict__ D = DQ;
+    const double *__restrict__ Q = DQ + 64;
+
+    // ---- fetch column x of the 8-row strip, form the residual, convert -----
+    double X[3][8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int B = 0, G = 0, R = 0;
+        if (live) {
+            const int y = ty * 8 + k;
+            const uint8_t *p = img + (size_t)y * g.pitch + (size_t)(3 * x);
+            B = p[0];
+            G = p[1];
+            R = p[2];
+            if (MODE == 1) {  // residual = cur - pred, uint8 wrap (motion.py:39)
+                int p0, p1, p2;
+                pred_px(ref, mv, g, y, x, p0, p1, p2);
+                B = (B - p0) & 255;
+                G = (G - p1) & 255;
+                R = (R - p2) & 255;
+            }
+        }
+        int Y, Cr, Cb;
+        bgr2ycc(B, G, R, Y, Cr, Cb);  // DCTcompressor.py:55
+        X[0][k] = (double)(Y - 128);  // :57-59
+        X[1][k] = (double)(Cr - 128);
+        X[2][k] = (double)(Cb - 128);
+    }
+
+    const size_t plane = (size_t)g.H * g.W;
+    typename CoeffT<CM>::type *__restrict__ out = planes + (size_t)f * planes_stride;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        // stage 1: T = D * X (DCTcompressor.py:113), lane holds column j
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc = __builtin_fma(D[i * 8 + k], X[ch][k], acc);
+            s_t[t * kTilePad + i * 8 + j] = acc;
+        }
+        __syncthreads();
+        // stage 2: R = T * D^T (:114), lane (t, i = j) holds row i of T
+        double T[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) T[k] = s_t[t * kTilePad + j * 8 + k];
+        __syncthreads();
+        if (live) {
+            const int xo = gx * 64 + t * 8;
+            typename CoeffT<CM>::type *o = out + ch * plane + (size_t)(ty * 8 + j) * g.W + xo;
+            const double *q = Q + ch * 64 + j * 8;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc = __builtin_fma(T[k], D[jj * 8 + k], acc);
+                o[jj] = coeff_pack<CM>(acc / q[jj]);  // :71 np.true_divide
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
+// k_idct: DCTCompressor.decompress (DCTcompressor.py:76-93); MODE 1 adds the
+// motion-compensated prediction with uint8 wrap (decoder.py:52-69).
+// --------------------------------------------------------------------------
+template <int MODE, int CM>
+__global__ __launch_bounds__(64) void k_idct(
+    const typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride,
+    const uint8_t *__restrict__ ref, const int16_t *__restrict__ mvs, Geom g,
+    const double *__restrict__ DQ, uint8_t *__restrict__ outs, size_t out_stride) {
+    __shared__ double s_t[8 * kTilePad];
+    const int lane = threadIdx.x;
+    const int t = lane >> 3, j = lane & 7;
+    const int groups_x = (g.W + 63) >> 6;
+    const int ty = blockIdx.x / groups_x, gx = blockIdx.x - ty * groups_x;
+    const int f = blockIdx.y;
+    const int x = gx * 64 + lane;
+    const bool live = x < g.W;
+    const size_t plane = (size_t)g.H * g.W;
+    const typename CoeffT<CM>::type *__restrict__ in = planes + (size_t)f * planes_stride;
+    const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
+    const double *__restrict__ D = DQ;
+    const double *__restrict__ Q = DQ + 64;
+
+    int ycc[3][8];  // row i = j of the tile, 8 pixels, after stage 2
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        double X[8];  // column j of the dequantised tile (:86 np.multiply)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            double v = 0.0;
+            if (live) v = (double)in[ch * plane + (size_t)(ty * 8 + k) * g.W + x];
+            X[k] = v * Q[ch * 64 + k * 8 + j];
+        }
+        // stage 1: T = D^T * X (:119)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc = __builtin_fma(D[k * 8 + i], X[k], acc);
+            s_t[t * kTilePad + i * 8 + j] = acc;
+        }
+        __syncthreads();
+        double T[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) T[k] = s_t[t * kTilePad + j * 8 + k];
+        __syncthreads();
+        // stage 2: R = T * D (:120); truncating uint8 store (:88), + 128 (:89)
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc = __builtin_fma(T[k], D[k * 8 + jj], acc);
+            ycc[ch][jj] = ((int)acc + 128) & 255;
+        }
+    }
+    if (!live) return;
+    const int y = ty * 8 + j, xo = gx * 64 + t * 8;
+    uint8_t *o = outs + (size_t)f * out_stride + (size_t)y * g.pitch + (size_t)(3 * xo);
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        int B, G, R;
+        ycc2bgr(ycc[0][jj], ycc[1][jj], ycc[2][jj], B, G, R);  // :92
+        if (MODE == 1) {  // decoder.py:57 img + decompressed, uint8 wrap
+            int p0, p1, p2;
+            pred_px(ref, mv, g, y, xo + jj, p0, p1, p2);
+            B = (B + p0) & 255;
+            G = (G + p1) & 255;
+            R = (R + p2) & 255;
+        }
+        o[3 * jj + 0] = (uint8_t)B;
+        o[3 * jj + 1] = (uint8_t)G;
+        o[3 * jj + 2] = (uint8_t)R;
+    }
+}
+
+// --------------------------------------------------------------------------
+// Stand-alone pieces of the class API (not on the fused path).
+// --------------------------------------------------------------------------
+// MotionProcessor.reconstruct_from_motion_vectors (motion.py:42-69): one
+// wavefront per block copies bs rows of 3*bs bytes.  `pred` is pre-zeroed.
+__global__ __launch_bounds__(64) void k_mc(const uint8_t *__restrict__ ref,
+                                           const int16_t *__restrict__ mv,
+                                           const int32_t *__restrict__ coords, Geom g,
+                                           uint8_t *__restrict__ pred) {
+    const int k = blockIdx.x, rowb = 3 * g.bs;
+    const int x = coords ? coords[2 * k] : (k % g.nbx) * g.bs;
+    const int y = coords ? coords[2 * k + 1] : (k / g.nbx) * g.bs;
+    const int sx = x + mv[2 * k], sy = y + mv[2 * k + 1];  // :60-61
+    for (int e = threadIdx.x; e < g.bs * rowb; e += 64) {
+        int r = e / rowb, b = e - r * rowb;
+        pred[(size_t)(y + r) * g.pitch + (size_t)(3 * x + b)] =
+            ref[(size_t)(sy + r) * g.pitch + (size_t)(3 * sx + b)];
+    }
+}
+
+// MotionProcessor.get_residuals (motion.py:38-40) and the decoder's wrap-add
+// (decoder.py:57,60): out = a -/+ b per byte; 16 bytes per lane per step.
+template <int SIGN>
+__global__ __launch_bounds__(256) void k_bytes_addsub(const uint8_t *__restrict__ a,
+                                                      const uint8_t *__restrict__ b,
+                                                      size_t n, uint8_t *__restrict__ out) {
+    const size_t nv = n >> 4;
+    const uint4 *a4 = (const uint4 *)a, *b4 = (const uint4 *)b;
+    uint4 *o4 = (uint4 *)out;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+         i += (size_t)gridDim.x * blockDim.x) {
+        uint4 va = a4[i], vb = b4[i], vo;
+        if (SIGN < 0) {
+            vo.x = sub_u8x4(va.x, vb.x); vo.y = sub_u8x4(va.y, vb.y);
+            vo.z = sub_u8x4(va.z, vb.z); vo.w = sub_u8x4(va.w, vb.w);
+        } else {
+            vo.x = add_u8x4(va.x, vb.x); vo.y = add_u8x4(va.y, vb.y);
+            vo.z = add_u8x4(va.z, vb.z); vo.w = add_u8x4(va.w, vb.w);
+        }
+        o4[i] = vo;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = (nv << 4) + threadIdx.x; i < n; i += blockDim.x)
+            out[i] = SIGN < 0 ? (uint8_t)(a[i] - b[i]) : (uint8_t)(a[i] + b[i]);
+}
+
+}  // namespace vcs

@@ -1,0 +1,816 @@
+// vcs_api.hip -- the C ABI of libvcs_hip.so (include/vcs_hip.h): contexts, HBM
+// buffers, launch chains, timing.  Host C++ + HIP runtime only; no PyTorch.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vcs_hip.h"
+#include "dct_kernels.hpp"
+#include "me_fast.hpp"
+#include "me_kernels.hpp"
+
+using namespace vcs;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct EvPair {
+    hipEvent_t a, b;
+    int slot;
+};
+
+}  // namespace
+
+struct vcs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Geom g{};
+    int64_t thresh64 = 2000;
+    int coeff_mode = VCS_COEFF_F64;
+    size_t F = 0, Fs = 0;  // frame bytes, padded frame stride
+    size_t me_lds = 0;     // dynamic LDS of the generic ME kernel
+    bool ref_valid = false;
+    bool me_fast_ok = false;
+    // single-frame buffers
+    uint8_t *d_ref = nullptr, *d_cur = nullptr, *d_a = nullptr, *d_b = nullptr;
+    int16_t *d_mv = nullptr;
+    int32_t *d_coords = nullptr;
+    unsigned long long *d_cost = nullptr;
+    uint32_t *d_ns = nullptr;
+    void *d_planes = nullptr;
+    double *d_DQ = nullptr;  // D[64] + Q[192]
+    double hDQ[256];
+    // GOP buffers
+    int slots = 0;
+    bool gop_dec = false;
+    uint8_t *g_cur = nullptr, *g_dec = nullptr;
+    int16_t *g_mv = nullptr;
+    uint32_t *g_ns = nullptr;
+    void *g_planes = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<EvPair> pending;
+    std::vector<EvPair> pool;
+    double acc_ms[VCS_T_COUNT] = {0, 0, 0, 0};
+    uint64_t launches[VCS_T_COUNT] = {0, 0, 0, 0};
+    std::string err;
+};
+
+namespace {
+
+int fail(vcs_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                              \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return fail((c), VCS_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+size_t coeff_size(int mode) { return mode == VCS_COEFF_F64 ? 8 : mode == VCS_COEFF_F32 ? 4 : 2; }
+size_t planes_bytes(const vcs_ctx *c) { return (size_t)3 * c->g.H * c->g.W * coeff_size(c->coeff_mode); }
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// JPEG tables of DCTcompressor.py:11-27 (data; [1][5] of QY is 48 there).
+const int kQY[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  48,  60,  55,
+                     14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+                     18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                     49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const int kQC[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+                     24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                     99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                     99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+
+int py_round_div3(int bs) {  // Python round(bs / 3): half to even (motion.py:132)
+    return (int)nearbyint((double)bs / 3.0);
+}
+
+// LDS demand of k_me_generic for the current geometry; 0 if it cannot fit.
+size_t me_generic_lds(const Geom &g, int *wpitch_out) {
+    const int rowb = 3 * g.bs, cpitch = (rowb + 3) & ~3;
+    const int wpitch = ((3 * 2 * g.win + 3 + 3) & ~3) + 8;
+    size_t lds = round_up((size_t)g.bs * cpitch, 16) + (size_t)2 * g.win * wpitch + 16;
+    if (wpitch_out) *wpitch_out = wpitch;
+    return lds;
+}
+
+int refresh_me_geometry(vcs_ctx *c) {
+    Geom &g = c->g;
+    if (g.win < 1 || g.step < 1) return fail(c, VCS_E_ARG, "win and step must be >= 1");
+    size_t lds = me_generic_lds(g, &g.wpitch);
+    if (lds > 160 * 1024)
+        return fail(c, VCS_E_ARG, "search window (bs=%d win=%d) needs %zu B of LDS, > 160 KiB",
+                    g.bs, g.win, lds);
+    c->me_lds = lds;
+    g.thresh = c->thresh64 < 0 ? 0u
+               : c->thresh64 > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)c->thresh64;
+    g.never_static = c->thresh64 < 0;
+    c->me_fast_ok = me_fast_supported(g);
+    return VCS_OK;
+}
+
+// ---- timing brackets -----------------------------------------------------
+int t_begin(vcs_ctx *c, int slot, EvPair *ev) {
+    c->launches[slot]++;
+    if (!c->timing) return VCS_OK;
+    if (!c->pool.empty()) {
+        *ev = c->pool.back();
+        c->pool.pop_back();
+    } else {
+        HIP_TRY(c, hipEventCreate(&ev->a));
+        HIP_TRY(c, hipEventCreate(&ev->b));
+    }
+    ev->slot = slot;
+    HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+    return VCS_OK;
+}
+int t_end(vcs_ctx *c, EvPair *ev) {
+    HIP_TRY(c, hipGetLastError());
+    if (!c->timing) return VCS_OK;
+    HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+    c->pending.push_back(*ev);
+    return VCS_OK;
+}
+
+// ---- launches --------------------------------------------------------------
+template <int BS_T>
+int launch_me_generic_t(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride,
+                        int n, int16_t *mv, uint32_t *ns, unsigned long long *cost) {
+    auto kern = k_me_generic<BS_T>;
+    if (c->me_lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute((const void *)kern,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->me_lds));
+    hipLaunchKernelGGL(kern, dim3(c->g.N, n), dim3(64), c->me_lds, c->stream, ref, curs, stride,
+                       c->g, mv, ns, cost);
+    return VCS_OK;
+}
+
+// Motion search for n frames (frame f at curs + f*stride) against `ref`.
+int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride, int n,
+              int16_t *mv, uint32_t *ns, unsigned long long *cost, bool force_generic = false) {
+    if (c->g.N == 0 || n == 0) return VCS_OK;
+    HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
+    EvPair ev;
+    int rc = t_begin(c, VCS_T_ME, &ev);
+    if (rc) return rc;
+    if (c->me_fast_ok && !force_generic) {
+        rc = launch_me_fast(c->g, c->stream, ref, curs, stride, n, mv, ns, cost);
+        if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
+    } else {
+        switch (c->g.bs) {
+            case 16: rc = launch_me_generic_t<16>(c, ref, curs, stride, n, mv, ns, cost); break;
+            case 8: rc = launch_me_generic_t<8>(c, ref, curs, stride, n, mv, ns, cost); break;
+            case 4: rc = launch_me_generic_t<4>(c, ref, curs, stride, n, mv, ns, cost); break;
+            default: rc = launch_me_generic_t<0>(c, ref, curs, stride, n, mv, ns, cost); break;
+        }
+        if (rc) return rc;
+    }
+    return t_end(c, &ev);
+}
+
+template <int MODE>
+int launch_fdct(vcs_ctx *c, int tslot, const uint8_t *imgs, size_t stride, const uint8_t *ref,
+                const int16_t *mv, int n, void *planes, size_t pstride_elems) {
+    if (n == 0) return VCS_OK;
+    const Geom &g = c->g;
+    dim3 grid(((g.W + 63) / 64) * (g.H / 8), n), block(64);
+    EvPair ev;
+    int rc = t_begin(c, tslot, &ev);
+    if (rc) return rc;
+    switch (c->coeff_mode) {
+        case VCS_COEFF_F64:
+            hipLaunchKernelGGL((k_fdct<MODE, 0>), grid, block, 0, c->stream, imgs, stride, ref, mv,
+                               g, c->d_DQ, (double *)planes, pstride_elems);
+            break;
+        case VCS_COEFF_F32:
+            hipLaunchKernelGGL((k_fdct<MODE, 1>), grid, block, 0, c->stream, imgs, stride, ref, mv,
+                               g, c->d_DQ, (float *)planes, pstride_elems);
+            break;
+        default:
+            hipLaunchKernelGGL((k_fdct<MODE, 2>), grid, block, 0, c->stream, imgs, stride, ref, mv,
+                               g, c->d_DQ, (int16_t *)planes, pstride_elems);
+            break;
+    }
+    return t_end(c, &ev);
+}
+
+template <int MODE>
+int launch_idct(vcs_ctx *c, int tslot, const void *planes, size_t pstride_elems,
+                const uint8_t *ref, const int16_t *mv, int n, uint8_t *outs, size_t ostride) {
+    if (n == 0) return VCS_OK;
+    const Geom &g = c->g;
+    dim3 grid(((g.W + 63) / 64) * (g.H / 8), n), block(64);
+    EvPair ev;
+    int rc = t_begin(c, tslot, &ev);
+    if (rc) return rc;
+    switch (c->coeff_mode) {
+        case VCS_COEFF_F64:
+            hipLaunchKernelGGL((k_idct<MODE, 0>), grid, block, 0, c->stream, (const double *)planes,
+                               pstride_elems, ref, mv, g, c->d_DQ, outs, ostride);
+            break;
+        case VCS_COEFF_F32:
+            hipLaunchKernelGGL((k_idct<MODE, 1>), grid, block, 0, c->stream, (const float *)planes,
+                               pstride_elems, ref, mv, g, c->d_DQ, outs, ostride);
+            break;
+        default:
+            hipLaunchKernelGGL((k_idct<MODE, 2>), grid, block, 0, c->stream,
+                               (const int16_t *)planes, pstride_elems, ref, mv, g, c->d_DQ, outs,
+                               ostride);
+            break;
+    }
+    return t_end(c, &ev);
+}
+
+int launch_mc(vcs_ctx *c, const int16_t *mv, const int32_t *coords, int n, uint8_t *pred) {
+    HIP_TRY(c, hipMemsetAsync(pred, 0, c->F, c->stream));  // motion.py:45-46
+    if (n == 0) return VCS_OK;
+    EvPair ev;
+    int rc = t_begin(c, VCS_T_AUX, &ev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mc, dim3(n), dim3(64), 0, c->stream, c->d_ref, mv, coords, c->g, pred);
+    return t_end(c, &ev);
+}
+
+int launch_addsub(vcs_ctx *c, const uint8_t *a, const uint8_t *b, int sign, size_t n,
+                  uint8_t *out) {
+    if (n == 0) return VCS_OK;
+    size_t nv = n >> 4;
+    int blocks = (int)((nv + 255) / 256);
+    blocks = blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks;
+    EvPair ev;
+    int rc = t_begin(c, VCS_T_AUX, &ev);
+    if (rc) return rc;
+    if (sign < 0)
+        hipLaunchKernelGGL((k_bytes_addsub<-1>), dim3(blocks), dim3(256), 0, c->stream, a, b, n, out);
+    else
+        hipLaunchKernelGGL((k_bytes_addsub<1>), dim3(blocks), dim3(256), 0, c->stream, a, b, n, out);
+    return t_end(c, &ev);
+}
+
+int ensure_planes(vcs_ctx *c) {
+    if (c->d_planes) return VCS_OK;
+    // sized for the widest mode so a later vcs_set_params(coeff_mode) is free
+    HIP_TRY(c, hipMalloc(&c->d_planes, (size_t)3 * c->g.H * c->g.W * 8 + 64));
+    return VCS_OK;
+}
+
+int need_dct_geometry(vcs_ctx *c) {
+    if (c->g.H % 8 || c->g.W % 8)
+        return fail(c, VCS_E_ARG,
+                    "DCT path needs H and W to be multiples of 8 (got %dx%d): the reference "
+                    "resamples such frames with cv2.resize (DCTcompressor.py:52-53), which is "
+                    "not reproduced", c->g.H, c->g.W);
+    return VCS_OK;
+}
+
+// Host-side bounds check of motion vectors (+ optional coords): a faulting
+// kernel can reset the whole GPU, so nothing unchecked reaches k_mc / k_idct.
+int check_mv(vcs_ctx *c, const int16_t *mv, const int32_t *coords, int n) {
+    const Geom &g = c->g;
+    for (int k = 0; k < n; k++) {
+        int x = coords ? coords[2 * k] : (k % g.nbx) * g.bs;
+        int y = coords ? coords[2 * k + 1] : (k / g.nbx) * g.bs;
+        int sx = x + mv[2 * k], sy = y + mv[2 * k + 1];
+        if (x < 0 || y < 0 || x + g.bs > g.W || y + g.bs > g.H || sx < 0 || sy < 0 ||
+            sx + g.bs > g.W || sy + g.bs > g.H)
+            return fail(c, VCS_E_RANGE, "block %d at (%d,%d) with mv (%d,%d) leaves the frame", k,
+                        x, y, mv[2 * k], mv[2 * k + 1]);
+    }
+    return VCS_OK;
+}
+
+int use(vcs_ctx *c) {
+    if (!c) return fail(nullptr, VCS_E_ARG, "null context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return VCS_OK;
+}
+
+void free_gop(vcs_ctx *c) {
+    hipFree(c->g_cur); hipFree(c->g_dec); hipFree(c->g_mv); hipFree(c->g_ns); hipFree(c->g_planes);
+    c->g_cur = c->g_dec = nullptr; c->g_mv = nullptr; c->g_ns = nullptr; c->g_planes = nullptr;
+    c->slots = 0;
+}
+
+}  // namespace
+
+// ==========================================================================
+extern "C" {
+
+int vcs_abi_version(void) { return VCS_ABI_VERSION; }
+
+int vcs_device_count(int *n) {
+    if (!n) return fail(nullptr, VCS_E_ARG, "null pointer");
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) {
+        *n = 0;
+        return fail(nullptr, VCS_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *n = k;
+    return VCS_OK;
+}
+
+const char *vcs_last_error(const vcs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int vcs_dct_matrix(double *D) {
+    if (!D) return fail(nullptr, VCS_E_ARG, "null pointer");
+    const int n = 8;  // DCTcompressor.py:124-133, same expression order
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            D[i * n + j] = i == 0 ? 1.0 / sqrt((double)n)
+                                  : sqrt(2.0 / (double)n) *
+                                        cos((double)((2 * j + 1) * i) * M_PI / (double)(2 * n));
+    return VCS_OK;
+}
+
+int vcs_make_q(double qf, double *Q) {
+    if (!Q) return fail(nullptr, VCS_E_ARG, "null pointer");
+    double scale;
+    if (qf < 50 && qf > 1) scale = 50 / qf;      // DCTcompressor.py:30-31
+    else if (qf < 100) scale = (100 - qf) / 50;  // :32-33
+    else return fail(nullptr, VCS_E_ARG, "Invalid quality setting, must be between 1 and 99.");
+    for (int i = 0; i < 64; i++) {
+        double y = nearbyint(kQY[i] * scale), cc = nearbyint(kQC[i] * scale);  // np.round
+        y = y < 1 ? 1 : y > 255 ? 255 : y;                                     // np.clip
+        cc = cc < 1 ? 1 : cc > 255 ? 255 : cc;
+        Q[i] = y;
+        Q[64 + i] = cc;
+        Q[128 + i] = cc;
+    }
+    return VCS_OK;
+}
+
+int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **out) {
+    if (!out) return fail(nullptr, VCS_E_ARG, "null out pointer");
+    *out = nullptr;
+    if (H < 1 || W < 1 || H > 16384 || W > 16384)
+        return fail(nullptr, VCS_E_ARG, "bad frame size %dx%d", H, W);
+    if (me_bs < 2 || me_bs > 128)
+        return fail(nullptr, VCS_E_ARG, "motion block size %d unsupported (2..128); note "
+                    "round(1/3) == 0 makes the reference raise for block size 1", me_bs);
+    if (dct_bs != 8)
+        return fail(nullptr, VCS_E_ARG, "DCT block size must be 8: the reference's Q tables are "
+                    "8x8 and np.true_divide raises for any other size (DCTcompressor.py:71)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, VCS_E_HIP, "no usable HIP device (%s); libvcs_hip has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, VCS_E_ARG, "device %d out of range (have %d)", device, ndev);
+    vcs_ctx *c = new (std::nothrow) vcs_ctx();
+    if (!c) return fail(nullptr, VCS_E_NOMEM, "out of host memory");
+    c->device = device;
+    Geom &g = c->g;
+    g.H = H; g.W = W; g.pitch = 3 * W; g.bs = me_bs;
+    g.nbx = W / me_bs; g.nby = H / me_bs; g.N = g.nbx * g.nby;
+    g.win = 2 * me_bs;               // motion.py:18
+    g.step = py_round_div3(me_bs);   // motion.py:132
+    c->thresh64 = 2000;              // motion.py:8
+    c->F = (size_t)3 * H * W;
+    c->Fs = round_up(c->F + 16, 256);
+    int rc = refresh_me_geometry(c);
+    if (rc) { g_err = c->err; delete c; return rc; }
+#define CREATE_TRY(expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e2 = (expr);                                                            \
+        if (e2 != hipSuccess) {                                                            \
+            fail(nullptr, e2 == hipErrorOutOfMemory ? VCS_E_NOMEM : VCS_E_HIP, "%s failed: %s", \
+                 #expr, hipGetErrorString(e2));                                            \
+            vcs_ctx_destroy(c);                                                            \
+            return e2 == hipErrorOutOfMemory ? VCS_E_NOMEM : VCS_E_HIP;                    \
+        }                                                                                  \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc(&c->d_ref, c->Fs));
+    CREATE_TRY(hipMalloc(&c->d_cur, c->Fs));
+    CREATE_TRY(hipMalloc(&c->d_a, c->Fs));
+    CREATE_TRY(hipMalloc(&c->d_b, c->Fs));
+    CREATE_TRY(hipMemset(c->d_ref, 0, c->Fs));
+    CREATE_TRY(hipMemset(c->d_cur, 0, c->Fs));
+    size_t nmv = (size_t)(g.N > 0 ? g.N : 1);
+    CREATE_TRY(hipMalloc(&c->d_mv, nmv * 2 * sizeof(int16_t)));
+    CREATE_TRY(hipMalloc(&c->d_coords, nmv * 2 * sizeof(int32_t)));
+    CREATE_TRY(hipMalloc(&c->d_cost, nmv * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(&c->d_ns, sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&c->d_DQ, sizeof(double) * 256));
+#undef CREATE_TRY
+    vcs_dct_matrix(c->hDQ);
+    vcs_make_q(50.0, c->hDQ + 64);  // DCTcompressor.py:29
+    hipError_t e3 = hipMemcpy(c->d_DQ, c->hDQ, sizeof(double) * 256, hipMemcpyHostToDevice);
+    if (e3 != hipSuccess) {
+        fail(nullptr, VCS_E_HIP, "hipMemcpy(DQ): %s", hipGetErrorString(e3));
+        vcs_ctx_destroy(c);
+        return VCS_E_HIP;
+    }
+    *out = c;
+    return VCS_OK;
+}
+
+int vcs_ctx_destroy(vcs_ctx *c) {
+    if (!c) return VCS_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto &p : c->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    free_gop(c);
+    hipFree(c->d_ref); hipFree(c->d_cur); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_mv);
+    hipFree(c->d_coords); hipFree(c->d_cost); hipFree(c->d_ns); hipFree(c->d_planes);
+    hipFree(c->d_DQ);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return VCS_OK;
+}
+
+int vcs_set_params(vcs_ctx *c, int win, int step, int64_t sim_thresh, const double *Q,
+                   int coeff_mode) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (coeff_mode < VCS_COEFF_F64 || coeff_mode > VCS_COEFF_I16)
+        return fail(c, VCS_E_ARG, "bad coeff_mode %d", coeff_mode);
+    if (Q)
+        for (int i = 0; i < 192; i++)
+            if (!(Q[i] == Q[i]) || Q[i] == 0.0 || fabs(Q[i]) > 1e300)
+                return fail(c, VCS_E_ARG, "Q[%d] must be finite and non-zero", i);
+    Geom saved = c->g;
+    int64_t saved_t = c->thresh64;
+    if (win > 0) c->g.win = win;
+    if (step > 0) c->g.step = step;
+    c->thresh64 = sim_thresh;
+    rc = refresh_me_geometry(c);
+    if (rc) {
+        c->g = saved;
+        c->thresh64 = saved_t;
+        refresh_me_geometry(c);
+        return rc;
+    }
+    if (coeff_mode != c->coeff_mode && c->slots)
+        return fail(c, VCS_E_STATE, "coeff_mode cannot change while GOP slots are reserved");
+    c->coeff_mode = coeff_mode;
+    if (Q) {
+        memcpy(c->hDQ + 64, Q, sizeof(double) * 192);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(c->d_DQ, c->hDQ, sizeof(double) * 256, hipMemcpyHostToDevice));
+    }
+    return VCS_OK;
+}
+
+int vcs_set_ref(vcs_ctx *c, const uint8_t *ref) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!ref) return fail(c, VCS_E_ARG, "null reference frame");
+    HIP_TRY(c, hipMemcpyAsync(c->d_ref, ref, c->F, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->ref_valid = true;
+    return VCS_OK;
+}
+
+int vcs_me(vcs_ctx *c, const uint8_t *cur, int16_t *mv_out, uint32_t *n_static,
+           uint64_t *cost_out) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!cur || !mv_out) return fail(c, VCS_E_ARG, "null pointer");
+    if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
+    HIP_TRY(c, hipMemcpyAsync(c->d_cur, cur, c->F, hipMemcpyHostToDevice, c->stream));
+    rc = launch_me(c, c->d_ref, c->d_cur, c->Fs, 1, c->d_mv, c->d_ns, cost_out ? c->d_cost : nullptr);
+    if (rc) return rc;
+    size_t N = c->g.N;
+    if (N) HIP_TRY(c, hipMemcpyAsync(mv_out, c->d_mv, N * 4, hipMemcpyDeviceToHost, c->stream));
+    uint32_t ns = 0;
+    if (N) HIP_TRY(c, hipMemcpyAsync(&ns, c->d_ns, 4, hipMemcpyDeviceToHost, c->stream));
+    if (cost_out && N)
+        HIP_TRY(c, hipMemcpyAsync(cost_out, c->d_cost, N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_static) *n_static = ns;
+    return VCS_OK;
+}
+
+int vcs_mc(vcs_ctx *c, const int16_t *mv, const int32_t *coords, int n, uint8_t *pred_out) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!pred_out || (n > 0 && !mv)) return fail(c, VCS_E_ARG, "null pointer");
+    if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
+    if (n < 0 || (!coords && n != c->g.N) || (coords && n > c->g.N))
+        return fail(c, VCS_E_ARG, "n = %d does not match the block grid (N = %d)", n, c->g.N);
+    rc = check_mv(c, mv, coords, n);
+    if (rc) return rc;
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->d_mv, mv, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (coords && n)
+        HIP_TRY(c, hipMemcpyAsync(c->d_coords, coords, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    rc = launch_mc(c, c->d_mv, coords ? c->d_coords : nullptr, n, c->d_a);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(pred_out, c->d_a, c->F, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_residual(vcs_ctx *c, const uint8_t *a, const uint8_t *b, int sign, size_t n,
+                 uint8_t *out) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!a || !b || !out) return fail(c, VCS_E_ARG, "null pointer");
+    if (n > c->F) return fail(c, VCS_E_ARG, "n = %zu exceeds the frame size %zu", n, c->F);
+    HIP_TRY(c, hipMemcpyAsync(c->d_a, a, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_b, b, n, hipMemcpyHostToDevice, c->stream));
+    rc = launch_addsub(c, c->d_a, c->d_b, sign, n, c->d_cur);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_cur, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_compress(vcs_ctx *c, const uint8_t *bgr, void *planes_out) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!bgr || !planes_out) return fail(c, VCS_E_ARG, "null pointer");
+    if ((rc = need_dct_geometry(c)) || (rc = ensure_planes(c))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_a, bgr, c->F, hipMemcpyHostToDevice, c->stream));
+    rc = launch_fdct<0>(c, VCS_T_AUX, c->d_a, c->Fs, nullptr, nullptr, 1, c->d_planes, 0);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(planes_out, c->d_planes, planes_bytes(c), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_decompress(vcs_ctx *c, const void *planes_in, uint8_t *bgr_out) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!planes_in || !bgr_out) return fail(c, VCS_E_ARG, "null pointer");
+    if ((rc = need_dct_geometry(c)) || (rc = ensure_planes(c))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_planes, planes_in, planes_bytes(c), hipMemcpyHostToDevice, c->stream));
+    rc = launch_idct<0>(c, VCS_T_AUX, c->d_planes, 0, nullptr, nullptr, 1, c->d_a, c->Fs);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(bgr_out, c->d_a, c->F, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_encode_p(vcs_ctx *c, const uint8_t *cur, int16_t *mv_out, void *planes_out,
+                 uint8_t *res_out, uint32_t *n_static) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!cur || !mv_out) return fail(c, VCS_E_ARG, "null pointer");
+    if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
+    if (planes_out && ((rc = need_dct_geometry(c)) || (rc = ensure_planes(c)))) return rc;
+    size_t N = c->g.N;
+    HIP_TRY(c, hipMemcpyAsync(c->d_cur, cur, c->F, hipMemcpyHostToDevice, c->stream));
+    rc = launch_me(c, c->d_ref, c->d_cur, c->Fs, 1, c->d_mv, c->d_ns, nullptr);
+    if (rc) return rc;
+    if (planes_out) {
+        rc = launch_fdct<1>(c, VCS_T_ENC_TAIL, c->d_cur, c->Fs, c->d_ref, c->d_mv, 1, c->d_planes, 0);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpyAsync(planes_out, c->d_planes, planes_bytes(c), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (res_out) {  // with_DCT = False (encoder.py:64-66): the raw uint8 residual
+        rc = launch_mc(c, c->d_mv, nullptr, (int)N, c->d_a);
+        if (!rc) rc = launch_addsub(c, c->d_cur, c->d_a, -1, c->F, c->d_b);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpyAsync(res_out, c->d_b, c->F, hipMemcpyDeviceToHost, c->stream));
+    }
+    uint32_t ns = 0;
+    if (N) {
+        HIP_TRY(c, hipMemcpyAsync(mv_out, c->d_mv, N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&ns, c->d_ns, 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_static) *n_static = ns;
+    return VCS_OK;
+}
+
+int vcs_decode_p(vcs_ctx *c, const int16_t *mv, const void *planes, uint8_t *bgr_out) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!bgr_out || (c->g.N > 0 && !mv)) return fail(c, VCS_E_ARG, "null pointer");
+    if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
+    rc = check_mv(c, mv, nullptr, c->g.N);
+    if (rc) return rc;
+    size_t N = c->g.N;
+    if (N) HIP_TRY(c, hipMemcpyAsync(c->d_mv, mv, N * 4, hipMemcpyHostToDevice, c->stream));
+    if (planes) {
+        if ((rc = need_dct_geometry(c)) || (rc = ensure_planes(c))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->d_planes, planes, planes_bytes(c), hipMemcpyHostToDevice, c->stream));
+        rc = launch_idct<1>(c, VCS_T_DEC, c->d_planes, 0, c->d_ref, c->d_mv, 1, c->d_a, c->Fs);
+    } else {
+        rc = launch_mc(c, c->d_mv, nullptr, (int)N, c->d_a);
+    }
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(bgr_out, c->d_a, c->F, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+// ---- GOP path ------------------------------------------------------------
+int vcs_gop_reserve(vcs_ctx *c, int n_slots, int with_decode) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (n_slots < 1 || n_slots > 4096) return fail(c, VCS_E_ARG, "bad slot count %d", n_slots);
+    if ((rc = need_dct_geometry(c))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_gop(c);
+    size_t nmv = (size_t)(c->g.N > 0 ? c->g.N : 1);
+    hipError_t e = hipMalloc(&c->g_cur, c->Fs * n_slots);
+    if (e == hipSuccess) e = hipMalloc(&c->g_mv, nmv * 4 * n_slots);
+    if (e == hipSuccess) e = hipMalloc(&c->g_ns, sizeof(uint32_t) * n_slots);
+    if (e == hipSuccess) e = hipMalloc(&c->g_planes, planes_bytes(c) * n_slots + 64);
+    if (e == hipSuccess && with_decode) e = hipMalloc(&c->g_dec, c->Fs * n_slots);
+    if (e == hipSuccess) e = hipMemset(c->g_cur, 0, c->Fs * n_slots);
+    if (e == hipSuccess) e = hipMemset(c->g_mv, 0, nmv * 4 * n_slots);
+    if (e == hipSuccess) e = hipMemset(c->g_ns, 0, sizeof(uint32_t) * n_slots);
+    if (e != hipSuccess) {
+        free_gop(c);
+        return fail(c, e == hipErrorOutOfMemory ? VCS_E_NOMEM : VCS_E_HIP, "GOP reserve: %s",
+                    hipGetErrorString(e));
+    }
+    c->slots = n_slots;
+    c->gop_dec = with_decode != 0;
+    return VCS_OK;
+}
+
+static int slot_range(vcs_ctx *c, int first, int n) {
+    if (first < 0 || n < 0 || first + n > c->slots)
+        return fail(c, VCS_E_ARG, "slots [%d, %d) outside the %d reserved", first, first + n, c->slots);
+    return VCS_OK;
+}
+
+int vcs_gop_upload(vcs_ctx *c, int first, int n, const uint8_t *frames) {
+    int rc = use(c);
+    if (rc || (rc = slot_range(c, first, n))) return rc;
+    if (!frames) return fail(c, VCS_E_ARG, "null pointer");
+    // host frames are packed at F, HBM slots sit at the padded stride Fs
+    HIP_TRY(c, hipMemcpy2DAsync(c->g_cur + (size_t)first * c->Fs, c->Fs, frames, c->F, c->F, n,
+                                hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_gop_encode(vcs_ctx *c, int first, int n) {
+    int rc = use(c);
+    if (rc || (rc = slot_range(c, first, n))) return rc;
+    if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
+    size_t N = c->g.N;
+    const uint8_t *curs = c->g_cur + (size_t)first * c->Fs;
+    int16_t *mv = c->g_mv + (size_t)first * N * 2;
+    rc = launch_me(c, c->d_ref, curs, c->Fs, n, mv, c->g_ns + first, nullptr);
+    if (rc) return rc;
+    size_t pe = (size_t)3 * c->g.H * c->g.W;
+    void *planes = (char *)c->g_planes + (size_t)first * planes_bytes(c);
+    return launch_fdct<1>(c, VCS_T_ENC_TAIL, curs, c->Fs, c->d_ref, mv, n, planes, pe);
+}
+
+int vcs_gop_decode(vcs_ctx *c, int first, int n) {
+    int rc = use(c);
+    if (rc || (rc = slot_range(c, first, n))) return rc;
+    if (!c->gop_dec) return fail(c, VCS_E_STATE, "GOP slots were reserved without decode buffers");
+    if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
+    size_t N = c->g.N, pe = (size_t)3 * c->g.H * c->g.W;
+    const void *planes = (const char *)c->g_planes + (size_t)first * planes_bytes(c);
+    return launch_idct<1>(c, VCS_T_DEC, planes, pe, c->d_ref, c->g_mv + (size_t)first * N * 2, n,
+                          c->g_dec + (size_t)first * c->Fs, c->Fs);
+}
+
+int vcs_gop_get_mv(vcs_ctx *c, int first, int n, int16_t *mv_out, uint32_t *ns_out) {
+    int rc = use(c);
+    if (rc || (rc = slot_range(c, first, n))) return rc;
+    size_t N = c->g.N;
+    if (mv_out && N && n)
+        HIP_TRY(c, hipMemcpyAsync(mv_out, c->g_mv + (size_t)first * N * 2, (size_t)n * N * 4,
+                                  hipMemcpyDeviceToHost, c->stream));
+    if (ns_out && n)
+        HIP_TRY(c, hipMemcpyAsync(ns_out, c->g_ns + first, sizeof(uint32_t) * n,
+                                  hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_gop_get_planes(vcs_ctx *c, int slot, void *planes_out) {
+    int rc = use(c);
+    if (rc || (rc = slot_range(c, slot, 1))) return rc;
+    if (!planes_out) return fail(c, VCS_E_ARG, "null pointer");
+    HIP_TRY(c, hipMemcpyAsync(planes_out, (const char *)c->g_planes + (size_t)slot * planes_bytes(c),
+                              planes_bytes(c), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_gop_get_decoded(vcs_ctx *c, int slot, uint8_t *bgr_out) {
+    int rc = use(c);
+    if (rc || (rc = slot_range(c, slot, 1))) return rc;
+    if (!bgr_out) return fail(c, VCS_E_ARG, "null pointer");
+    if (!c->gop_dec) return fail(c, VCS_E_STATE, "GOP slots were reserved without decode buffers");
+    HIP_TRY(c, hipMemcpyAsync(bgr_out, c->g_dec + (size_t)slot * c->Fs, c->F, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_sync(vcs_ctx *c) {
+    int rc = use(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_dev_ptr(vcs_ctx *c, int which, void **ptr, size_t *bytes) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!ptr) return fail(c, VCS_E_ARG, "null pointer");
+    size_t nmv = (size_t)(c->g.N > 0 ? c->g.N : 1), b = 0;
+    void *p = nullptr;
+    switch (which) {
+        case 0: p = c->d_ref; b = c->F; break;
+        case 1: p = c->g_mv; b = nmv * 4 * c->slots; break;
+        case 2: p = c->g_ns; b = sizeof(uint32_t) * c->slots; break;
+        default: return fail(c, VCS_E_ARG, "bad buffer id %d", which);
+    }
+    if (!p) return fail(c, VCS_E_STATE, "buffer %d not allocated (vcs_gop_reserve first)", which);
+    *ptr = p;
+    if (bytes) *bytes = b;
+    return VCS_OK;
+}
+
+int vcs_ref_written(vcs_ctx *c) {
+    int rc = use(c);
+    if (rc) return rc;
+    c->ref_valid = true;
+    return VCS_OK;
+}
+
+// ---- measurement -----------------------------------------------------------
+int vcs_timing_enable(vcs_ctx *c, int on) {
+    int rc = use(c);
+    if (rc) return rc;
+    c->timing = on != 0;
+    return VCS_OK;
+}
+
+static int drain_events(vcs_ctx *c) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto &p : c->pending) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, p.a, p.b));
+        c->acc_ms[p.slot] += ms;
+        c->pool.push_back(p);
+    }
+    c->pending.clear();
+    return VCS_OK;
+}
+
+int vcs_timing_reset(vcs_ctx *c) {
+    int rc = use(c);
+    if (rc || (rc = drain_events(c))) return rc;
+    for (int i = 0; i < VCS_T_COUNT; i++) { c->acc_ms[i] = 0; c->launches[i] = 0; }
+    return VCS_OK;
+}
+
+int vcs_timing(vcs_ctx *c, double *ms_out, uint64_t *launches_out, int n) {
+    int rc = use(c);
+    if (rc || (rc = drain_events(c))) return rc;
+    for (int i = 0; i < n && i < VCS_T_COUNT; i++) {
+        if (ms_out) ms_out[i] = c->acc_ms[i];
+        if (launches_out) launches_out[i] = c->launches[i];
+    }
+    return VCS_OK;
+}
+
+int vcs_measure_copy_bw(vcs_ctx *c, size_t bytes, int iters, double *gbps_out) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!gbps_out || bytes < 1024 || iters < 1) return fail(c, VCS_E_ARG, "bad arguments");
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipMalloc(&a, bytes));
+    hipError_t e = hipMalloc(&b, bytes);
+    if (e != hipSuccess) { hipFree(a); return fail(c, VCS_E_NOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
+    hipMemsetAsync(a, 1, bytes, c->stream);
+    hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, c->stream);  // warm
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, c->stream);
+    for (int i = 0; i < iters; i++) hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, c->stream);
+    hipEventRecord(e1, c->stream);
+    e = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a); hipFree(b);
+    if (e != hipSuccess) return fail(c, VCS_E_HIP, "copy benchmark: %s", hipGetErrorString(e));
+    *gbps_out = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;  // read + write
+    return VCS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// vcs_common.hpp -- shared device helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vcs {
+
+// Frame / block geometry shared by all kernels (filled on the host).
+struct Geom {
+    int H, W;        // frame size in pixels
+    int pitch;       // bytes per frame row = 3 * W
+    int bs;          // motion block size
+    int nbx, nby, N; // full blocks per row / column / frame (motion.py:74-98)
+    int win, step;   // search half-window and stride (motion.py:18, :132)
+    uint32_t thresh; // static threshold (motion.py:8), clamped to u32
+    int never_static;// thresh < 0: no block can be static
+    int wpitch;      // LDS bytes per staged window row (generic ME kernel)
+};
+
+// ---- wave64 reductions ---------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+// ---- packed-byte arithmetic ---------------------------------------------
+// Per-byte (a - b) mod 256 on four packed bytes, no borrow across bytes.
+__device__ __forceinline__ uint32_t sub_u8x4(uint32_t a, uint32_t b) {
+    const uint32_t Hm = 0x80808080u;
+    return ((a | Hm) - (b & ~Hm)) ^ ((a ^ ~b) & Hm);
+}
+// Per-byte (a + b) mod 256.
+__device__ __forceinline__ uint32_t add_u8x4(uint32_t a, uint32_t b) {
+    const uint32_t Hm = 0x80808080u;
+    return ((a & ~Hm) + (b & ~Hm)) ^ ((a ^ b) & Hm);
+}
+// acc + sum of the four bytes of v  (v_sad_u8 against zero).
+__device__ __forceinline__ uint32_t bytesum_acc(uint32_t v, uint32_t acc) {
+    return __builtin_amdgcn_sad_u8(v, 0u, acc);
+}
+
+// ---- OpenCV 8-bit BGR <-> YCrCb (cv2.cvtColor at DCTcompressor.py:55/:92) --
+// Restated from OpenCV 4.x imgproc/src/color_yuv.simd.hpp; third-party code,
+// parity unpinned against a real OpenCV binary.
+__device__ __forceinline__ int descale14(int v) { return (v + (1 << 13)) >> 14; }
+__device__ __forceinline__ int sat8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ void bgr2ycc(int B, int G, int R, int &Y, int &Cr, int &Cb) {
+    int y = descale14(R * 4899 + G * 9617 + B * 1868);
+    Cr = sat8(descale14((R - y) * 11682 + (128 << 14)));
+    Cb = sat8(descale14((B - y) * 9241 + (128 << 14)));
+    Y = sat8(y);
+}
+__device__ __forceinline__ void ycc2bgr(int Y, int Cr, int Cb, int &B, int &G, int &R) {
+    Cr -= 128;
+    Cb -= 128;
+    B = sat8(Y + descale14(Cb * 29049));
+    G = sat8(Y + descale14(Cb * -5636 + Cr * -11698));
+    R = sat8(Y + descale14(Cr * 22987));
+}
+
+}  // namespace vcs

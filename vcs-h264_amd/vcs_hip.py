@@ -1,0 +1,326 @@
+"""ctypes binding of libvcs_hip.so (include/vcs_hip.h) -- the only way the
+Python host code reaches the MI355X kernels.  No PyTorch, no CPU fallback:
+if the library or a GPU is missing, construction raises.
+
+`Context` is a thin object wrapper over the C handle; array arguments are
+NumPy arrays (uint8 frames, int16 motion vectors, float64 planes).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("VCS_HIP_LIB", os.path.join(_HERE, "lib", "libvcs_hip.so"))
+
+VCS_COEFF_F64, VCS_COEFF_F32, VCS_COEFF_I16 = 0, 1, 2
+COEFF_DTYPES = {0: np.float64, 1: np.float32, 2: np.int16}
+T_ME, T_ENC_TAIL, T_DEC, T_AUX, T_COUNT = 0, 1, 2, 3, 4
+
+_c_ctx = ctypes.c_void_p
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i16p = ctypes.POINTER(ctypes.c_int16)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes): every symbol include/vcs_hip.h declares
+SIGNATURES = {
+    "vcs_abi_version": (ctypes.c_int, []),
+    "vcs_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "vcs_last_error": (ctypes.c_char_p, [_c_ctx]),
+    "vcs_ctx_create": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(_c_ctx)]),
+    "vcs_ctx_destroy": (ctypes.c_int, [_c_ctx]),
+    "vcs_set_params": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _f64p,
+                                      ctypes.c_int]),
+    "vcs_make_q": (ctypes.c_int, [ctypes.c_double, _f64p]),
+    "vcs_dct_matrix": (ctypes.c_int, [_f64p]),
+    "vcs_set_ref": (ctypes.c_int, [_c_ctx, _u8p]),
+    "vcs_me": (ctypes.c_int, [_c_ctx, _u8p, _i16p, _u32p, _u64p]),
+    "vcs_mc": (ctypes.c_int, [_c_ctx, _i16p, _i32p, ctypes.c_int, _u8p]),
+    "vcs_residual": (ctypes.c_int, [_c_ctx, _u8p, _u8p, ctypes.c_int, ctypes.c_size_t, _u8p]),
+    "vcs_compress": (ctypes.c_int, [_c_ctx, _u8p, _vp]),
+    "vcs_decompress": (ctypes.c_int, [_c_ctx, _vp, _u8p]),
+    "vcs_encode_p": (ctypes.c_int, [_c_ctx, _u8p, _i16p, _vp, _u8p, _u32p]),
+    "vcs_decode_p": (ctypes.c_int, [_c_ctx, _i16p, _vp, _u8p]),
+    "vcs_gop_reserve": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
+    "vcs_gop_upload": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _u8p]),
+    "vcs_gop_encode": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
+    "vcs_gop_decode": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
+    "vcs_gop_get_mv": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _i16p, _u32p]),
+    "vcs_gop_get_planes": (ctypes.c_int, [_c_ctx, ctypes.c_int, _vp]),
+    "vcs_gop_get_decoded": (ctypes.c_int, [_c_ctx, ctypes.c_int, _u8p]),
+    "vcs_sync": (ctypes.c_int, [_c_ctx]),
+    "vcs_dev_ptr": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.POINTER(_vp),
+                                   ctypes.POINTER(ctypes.c_size_t)]),
+    "vcs_ref_written": (ctypes.c_int, [_c_ctx]),
+    "vcs_timing_enable": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
+    "vcs_timing_reset": (ctypes.c_int, [_c_ctx]),
+    "vcs_timing": (ctypes.c_int, [_c_ctx, _f64p, _u64p, ctypes.c_int]),
+    "vcs_measure_copy_bw": (ctypes.c_int, [_c_ctx, ctypes.c_size_t, ctypes.c_int, _f64p]),
+}
+
+_LIB = None
+
+
+class VcsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libvcs_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load(path=None):
+    """Load libvcs_hip.so and bind every declared symbol.  Raises OSError if the
+    library is missing -- there is deliberately no CPU fallback."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError("%s not found: build it with `python __graft_entry__.py build` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = load().vcs_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def make_q(qf=50.0):
+    """The Q list of DCTcompressor.py:29-38 for quality factor `qf` -> (3, 8, 8)."""
+    Q = np.zeros((3, 8, 8), np.float64)
+    rc = load().vcs_make_q(float(qf), Q.ctypes.data_as(_f64p))
+    if rc:
+        raise ValueError("Invalid quality setting, must be between 1 and 99.")
+    return Q
+
+
+def dct_matrix():
+    D = np.zeros((8, 8), np.float64)
+    load().vcs_dct_matrix(D.ctypes.data_as(_f64p))
+    return D
+
+
+def _frame(a, shape=None, name="frame"):
+    a = np.asarray(a)
+    if a.dtype != np.uint8:
+        raise TypeError("%s must be uint8, got %s" % (name, a.dtype))
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return np.ascontiguousarray(a)
+
+
+class Context:
+    """One HIP device context for frames of H x W (vcs_ctx_create)."""
+
+    def __init__(self, H, W, me_bs, dct_bs=8, device=0):
+        self._lib = load()
+        self._h = _c_ctx()
+        self.H, self.W, self.me_bs = int(H), int(W), int(me_bs)
+        rc = self._lib.vcs_ctx_create(int(device), self.H, self.W, self.me_bs, int(dct_bs),
+                                      ctypes.byref(self._h))
+        if rc:
+            self._h = _c_ctx()
+            raise VcsError(rc, (self._lib.vcs_last_error(None) or b"").decode())
+        self.N = (self.H // self.me_bs) * (self.W // self.me_bs)
+        self.F = 3 * self.H * self.W
+        self.shape = (self.H, self.W, 3)
+        self.coeff_mode = VCS_COEFF_F64
+        self.slots = 0
+
+    # -- plumbing ----------------------------------------------------------
+    def _ck(self, rc):
+        if rc:
+            raise VcsError(rc, (self._lib.vcs_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.vcs_ctx_destroy(self._h)
+            self._h = _c_ctx()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def coeff_dtype(self):
+        return COEFF_DTYPES[self.coeff_mode]
+
+    # -- parameters --------------------------------------------------------
+    def set_params(self, win=0, step=0, sim_thresh=2000, Q=None, coeff_mode=None):
+        cm = self.coeff_mode if coeff_mode is None else int(coeff_mode)
+        qp = None
+        if Q is not None:
+            Q = np.ascontiguousarray(np.asarray(Q, np.float64).reshape(3, 8, 8))
+            qp = Q.ctypes.data_as(_f64p)
+        self._ck(self._lib.vcs_set_params(self._h, int(win), int(step), int(sim_thresh), qp, cm))
+        self.coeff_mode = cm
+
+    # -- single-frame entry points ------------------------------------------
+    def set_ref(self, ref):
+        ref = _frame(ref, self.shape, "reference frame")
+        self._ck(self._lib.vcs_set_ref(self._h, ref.ctypes.data_as(_u8p)))
+
+    def me(self, cur, want_cost=False):
+        cur = _frame(cur, self.shape, "input frame")
+        mv = np.zeros((self.N, 2), np.int16)
+        ns = ctypes.c_uint32(0)
+        cost = np.zeros(self.N, np.uint64) if want_cost else None
+        self._ck(self._lib.vcs_me(self._h, cur.ctypes.data_as(_u8p), mv.ctypes.data_as(_i16p),
+                                  ctypes.byref(ns),
+                                  cost.ctypes.data_as(_u64p) if want_cost else None))
+        return (mv, ns.value, cost) if want_cost else (mv, ns.value)
+
+    def mc(self, mv, coords=None):
+        mv = np.ascontiguousarray(np.asarray(mv, np.int16).reshape(-1, 2))
+        cp = None
+        if coords is not None:
+            coords = np.ascontiguousarray(np.asarray(coords, np.int32).reshape(-1, 2))
+            if coords.shape[0] != mv.shape[0]:
+                raise ValueError("motion_vectors and block_coords differ in length")
+            cp = coords.ctypes.data_as(_i32p)
+        pred = np.zeros(self.shape, np.uint8)
+        self._ck(self._lib.vcs_mc(self._h, mv.ctypes.data_as(_i16p), cp, mv.shape[0],
+                                  pred.ctypes.data_as(_u8p)))
+        return pred
+
+    def residual(self, a, b, sign=-1):
+        a = _frame(a, name="a")
+        b = _frame(b, a.shape, "b")
+        out = np.zeros(a.shape, np.uint8)
+        self._ck(self._lib.vcs_residual(self._h, a.ctypes.data_as(_u8p), b.ctypes.data_as(_u8p),
+                                        int(sign), a.size, out.ctypes.data_as(_u8p)))
+        return out
+
+    def compress(self, bgr):
+        bgr = _frame(bgr, self.shape, "image")
+        planes = np.zeros((3, self.H, self.W), self.coeff_dtype)
+        self._ck(self._lib.vcs_compress(self._h, bgr.ctypes.data_as(_u8p),
+                                        planes.ctypes.data_as(_vp)))
+        return planes
+
+    def _planes_in(self, planes):
+        planes = np.ascontiguousarray(np.asarray(planes, self.coeff_dtype))
+        if planes.shape != (3, self.H, self.W):
+            raise ValueError("planes have shape %s, expected %s" %
+                             (planes.shape, (3, self.H, self.W)))
+        return planes
+
+    def decompress(self, planes):
+        planes = self._planes_in(planes)
+        out = np.zeros(self.shape, np.uint8)
+        self._ck(self._lib.vcs_decompress(self._h, planes.ctypes.data_as(_vp),
+                                          out.ctypes.data_as(_u8p)))
+        return out
+
+    def encode_p(self, cur, want_planes=True, want_res=False):
+        cur = _frame(cur, self.shape, "input frame")
+        mv = np.zeros((self.N, 2), np.int16)
+        planes = np.zeros((3, self.H, self.W), self.coeff_dtype) if want_planes else None
+        res = np.zeros(self.shape, np.uint8) if want_res else None
+        ns = ctypes.c_uint32(0)
+        self._ck(self._lib.vcs_encode_p(self._h, cur.ctypes.data_as(_u8p),
+                                        mv.ctypes.data_as(_i16p),
+                                        planes.ctypes.data_as(_vp) if want_planes else None,
+                                        res.ctypes.data_as(_u8p) if want_res else None,
+                                        ctypes.byref(ns)))
+        return mv, planes, res, ns.value
+
+    def decode_p(self, mv, planes=None):
+        mv = np.ascontiguousarray(np.asarray(mv, np.int16).reshape(-1, 2))
+        if mv.shape[0] != self.N:
+            raise ValueError("expected %d motion vectors, got %d" % (self.N, mv.shape[0]))
+        pp = None
+        if planes is not None:
+            planes = self._planes_in(planes)
+            pp = planes.ctypes.data_as(_vp)
+        out = np.zeros(self.shape, np.uint8)
+        self._ck(self._lib.vcs_decode_p(self._h, mv.ctypes.data_as(_i16p), pp,
+                                        out.ctypes.data_as(_u8p)))
+        return out
+
+    # -- GOP path -----------------------------------------------------------
+    def gop_reserve(self, n_slots, with_decode=False):
+        self._ck(self._lib.vcs_gop_reserve(self._h, int(n_slots), int(bool(with_decode))))
+        self.slots = int(n_slots)
+
+    def gop_upload(self, first, frames):
+        frames = np.asarray(frames)
+        if frames.dtype != np.uint8 or frames.shape[1:] != self.shape:
+            raise ValueError("frames must be uint8 of shape (n, %d, %d, 3)" % (self.H, self.W))
+        frames = np.ascontiguousarray(frames)
+        self._ck(self._lib.vcs_gop_upload(self._h, int(first), frames.shape[0],
+                                          frames.ctypes.data_as(_u8p)))
+
+    def gop_encode(self, first, n):
+        self._ck(self._lib.vcs_gop_encode(self._h, int(first), int(n)))
+
+    def gop_decode(self, first, n):
+        self._ck(self._lib.vcs_gop_decode(self._h, int(first), int(n)))
+
+    def gop_get_mv(self, first, n):
+        mv = np.zeros((n, self.N, 2), np.int16)
+        ns = np.zeros(n, np.uint32)
+        self._ck(self._lib.vcs_gop_get_mv(self._h, int(first), int(n), mv.ctypes.data_as(_i16p),
+                                          ns.ctypes.data_as(_u32p)))
+        return mv, ns
+
+    def gop_get_planes(self, slot):
+        planes = np.zeros((3, self.H, self.W), self.coeff_dtype)
+        self._ck(self._lib.vcs_gop_get_planes(self._h, int(slot), planes.ctypes.data_as(_vp)))
+        return planes
+
+    def gop_get_decoded(self, slot):
+        out = np.zeros(self.shape, np.uint8)
+        self._ck(self._lib.vcs_gop_get_decoded(self._h, int(slot), out.ctypes.data_as(_u8p)))
+        return out
+
+    def sync(self):
+        self._ck(self._lib.vcs_sync(self._h))
+
+    def dev_ptr(self, which):
+        p = _vp()
+        b = ctypes.c_size_t(0)
+        self._ck(self._lib.vcs_dev_ptr(self._h, int(which), ctypes.byref(p), ctypes.byref(b)))
+        return p.value, b.value
+
+    def ref_written(self):
+        self._ck(self._lib.vcs_ref_written(self._h))
+
+    # -- measurement --------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._ck(self._lib.vcs_timing_enable(self._h, int(bool(on))))
+
+    def timing_reset(self):
+        self._ck(self._lib.vcs_timing_reset(self._h))
+
+    def timing(self):
+        ms = np.zeros(T_COUNT, np.float64)
+        n = np.zeros(T_COUNT, np.uint64)
+        self._ck(self._lib.vcs_timing(self._h, ms.ctypes.data_as(_f64p), n.ctypes.data_as(_u64p),
+                                      T_COUNT))
+        return ms, n
+
+    def measure_copy_bw(self, nbytes=1 << 30, iters=10):
+        g = ctypes.c_double(0)
+        self._ck(self._lib.vcs_measure_copy_bw(self._h, int(nbytes), int(iters), ctypes.byref(g)))
+        return g.value
