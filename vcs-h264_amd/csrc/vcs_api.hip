@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -120,7 +121,9 @@ int refresh_me_geometry(vcs_ctx *c) {
     g.thresh = c->thresh64 < 0 ? 0u
                : c->thresh64 > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)c->thresh64;
     g.never_static = c->thresh64 < 0;
-    c->me_fast_ok = me_fast_supported(g);
+    // VCS_ME_GENERIC=1 forces the generic kernel (A/B measurements, debugging)
+    const char *force = getenv("VCS_ME_GENERIC");
+    c->me_fast_ok = me_fast_supported(g) && !(force && force[0] == '1');
     return VCS_OK;
 }
 
@@ -383,7 +386,7 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     g.step = py_round_div3(me_bs);   // motion.py:132
     c->thresh64 = 2000;              // motion.py:8
     c->F = (size_t)3 * H * W;
-    c->Fs = round_up(c->F + 16, 256);
+    c->Fs = round_up(c->F + 64, 256);  // slack: kernels may over-read a few bytes
     int rc = refresh_me_geometry(c);
     if (rc) { g_err = c->err; delete c; return rc; }
 #define CREATE_TRY(expr)                                                                   \
