@@ -24,12 +24,12 @@
 //   * 100 candidates = two passes of 64 lanes; both passes share each
 //     re-packed row of the current block.
 #pragma once
+#include <stdlib.h>
+
 #include "vcs_common.hpp"
 
 namespace vcs {
 
-constexpr int kMe16Slots = 18;                // 16-byte slots per LDS window row
-constexpr int kMe16RowB = kMe16Slots * 16;    // 288 bytes
 constexpr int kMe16Rows = 64;                 // 2 * win
 constexpr int kMe16Groups = 13;               // ceil(64 px / 5)
 
@@ -76,10 +76,13 @@ __device__ __forceinline__ void me16_row(const uint8_t *lds_row, const uint32_t 
     }
 }
 
+// SLOTS: 16-byte slots per LDS window row (18 = conflict-free, 13/14 = denser).
+template <int SLOTS>
 __global__ __launch_bounds__(64) void k_me16(
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
     Geom g, int16_t *__restrict__ mv, uint32_t *__restrict__ n_static,
     unsigned long long *__restrict__ cost_out) {
+    constexpr int kMe16RowB = SLOTS * 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_win[kMe16Rows * kMe16RowB];
     constexpr int BS = 16, WIN = 32, STEP = 5;
     const int lane = threadIdx.x;
@@ -89,18 +92,40 @@ __global__ __launch_bounds__(64) void k_me16(
     const int x = bxi * BS, y = byi * BS;
     const size_t blk_off = (size_t)y * g.pitch + (size_t)(48 * bxi);
 
+    // ---- issue every global load of this block up front -----------------------
+    // static-test operands (3 dwords per lane of the co-located ref / cur block)
+    uint32_t rv[3], cv[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int idx = lane + 64 * t, row = idx / 12, col = idx - row * 12;
+        const size_t off = blk_off + (size_t)row * g.pitch + (size_t)(4 * col);
+        rv[t] = *(const uint32_t *)(ref + off);
+        cv[t] = *(const uint32_t *)(cur + off);
+    }
+    // the search window (motion.py:125-129), fetched speculatively: 13 unaligned
+    // 16-byte loads per lane are in flight while the static test is evaluated
+    const int i_min = max(y - WIN, 0), j_min = max(x - WIN, 0);
+    const int i_max = min(y + WIN, g.H), j_max = min(x + WIN, g.W);
+    const int wrows = i_max - i_min;
+    const uint8_t *__restrict__ wsrc = ref + (size_t)i_min * g.pitch + (size_t)(3 * j_min);
+    uint4 stg[kMe16Groups];
+#pragma unroll
+    for (int t = 0; t < kMe16Groups; t++) {
+        const int e = lane + 64 * t, row = e / kMe16Groups, gi = e - row * kMe16Groups;
+        // rows past the clipped window are clamped (never read back), so the
+        // load is unconditional: a branch here would cost a vmcnt(0) per load
+        const int rc = min(row, wrows - 1);
+        stg[t] = load16_any_align(wsrc + (size_t)rc * g.pitch + (size_t)(15 * gi));
+    }
+
     // ---- static test (motion.py:109-116): sum(max(r - c, 0)) -------------------
     //   max(r - c, 0) = (|r - c| + r - c) / 2 per byte -> three v_sad_u8 per dword
     uint32_t s_abs = 0, s_r = 0, s_c = 0;
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-        const int idx = lane + 64 * t, row = idx / 12, col = idx - row * 12;
-        const size_t off = blk_off + (size_t)row * g.pitch + (size_t)(4 * col);
-        const uint32_t rv = *(const uint32_t *)(ref + off);
-        const uint32_t cv = *(const uint32_t *)(cur + off);
-        s_abs = __builtin_amdgcn_sad_u8(rv, cv, s_abs);
-        s_r = __builtin_amdgcn_sad_u8(rv, 0u, s_r);
-        s_c = __builtin_amdgcn_sad_u8(cv, 0u, s_c);
+        s_abs = __builtin_amdgcn_sad_u8(rv[t], cv[t], s_abs);
+        s_r = __builtin_amdgcn_sad_u8(rv[t], 0u, s_r);
+        s_c = __builtin_amdgcn_sad_u8(cv[t], 0u, s_c);
     }
     s_abs = wave_sum_u32(s_abs);
     s_r = wave_sum_u32(s_r);
@@ -117,16 +142,13 @@ __global__ __launch_bounds__(64) void k_me16(
         return;
     }
 
-    // ---- park the window in 5-pixel groups (motion.py:125-129) ------------------
-    const int i_min = max(y - WIN, 0), j_min = max(x - WIN, 0);
-    const int i_max = min(y + WIN, g.H), j_max = min(x + WIN, g.W);
-    const int wrows = i_max - i_min;
-    const uint8_t *__restrict__ wsrc = ref + (size_t)i_min * g.pitch + (size_t)(3 * j_min);
-    for (int e = lane; e < wrows * kMe16Groups; e += 64) {
-        const int row = e / kMe16Groups, gi = e - row * kMe16Groups;
-        uint4 v = load16_any_align(wsrc + (size_t)row * g.pitch + (size_t)(15 * gi));
+    // ---- park the window in 5-pixel groups ---------------------------------------
+#pragma unroll
+    for (int t = 0; t < kMe16Groups; t++) {
+        const int e = lane + 64 * t, row = e / kMe16Groups, gi = e - row * kMe16Groups;
+        uint4 v = stg[t];
         v.w &= 0x00FFFFFFu;  // pad byte = 0 so that it adds nothing to sum(r)
-        *(uint4 *)(s_win + row * kMe16RowB + gi * 16) = v;
+        if (row < kMe16Rows) *(uint4 *)(s_win + row * kMe16RowB + gi * 16) = v;
     }
     __syncthreads();
 
@@ -147,14 +169,18 @@ __global__ __launch_bounds__(64) void k_me16(
     uint32_t cnt0 = 0, sum0 = 0, cnt1 = 0, sum1 = 0;
     const uint32_t *__restrict__ crow = (const uint32_t *)(cur + blk_off);
     const int pitch_dw = g.pitch >> 2;
+    uint32_t d[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) d[i] = crow[i];
 #pragma unroll 4
     for (int k = 0; k < BS; k++) {
-        // current row k: 48 wave-uniform bytes -> scalar loads, re-packed into
-        // 5-pixel groups (pad byte -> ~c = 0xFF) on the scalar ALU
-        const uint32_t *cr = crow + (size_t)k * pitch_dw;
-        uint32_t d[12];
+        // current row k: 48 wave-uniform bytes -> scalar loads (row k+1 is
+        // requested before row k is consumed), re-packed into 5-pixel groups
+        // (pad byte -> ~c = 0xFF) on the scalar ALU
+        const uint32_t *cr = crow + (size_t)(k + 1 < BS ? k + 1 : k) * pitch_dw;
+        uint32_t dn[12];
 #pragma unroll
-        for (int i = 0; i < 12; i++) d[i] = cr[i];
+        for (int i = 0; i < 12; i++) dn[i] = cr[i];
         uint32_t nc[13];
         nc[0] = ~d[0];
         nc[1] = ~d[1];
@@ -171,6 +197,8 @@ __global__ __launch_bounds__(64) void k_me16(
         nc[12] = ~(d[11] >> 8) | 0xFF000000u;
         me16_row(p0 + k * kMe16RowB, nc, cnt0, sum0);
         if (two) me16_row(p1 + k * kMe16RowB, nc, cnt1, sum1);
+#pragma unroll
+        for (int i = 0; i < 12; i++) d[i] = dn[i];
     }
     // cost = sum(r) - sum(c) + 256 * #{r < c}; 64 pad bytes were always counted
     const uint32_t n_lt0 = 768u + 64u - cnt0, n_lt1 = 768u + 64u - cnt1;
@@ -205,8 +233,18 @@ inline bool me_fast_supported(const Geom &g) {
 inline int launch_me_fast(const Geom &g, hipStream_t stream, const uint8_t *ref,
                           const uint8_t *curs, size_t stride, int n, int16_t *mv, uint32_t *ns,
                           unsigned long long *cost) {
-    hipLaunchKernelGGL(k_me16, dim3(g.N, n), dim3(64), 0, stream, ref, curs, stride, g, mv, ns,
-                       cost);
+    static const int slots = [] {
+        const char *e = getenv("VCS_ME16_SLOTS");  // tuning knob: 13, 14 or 18
+        int v = e ? atoi(e) : 18;
+        return (v == 13 || v == 14) ? v : 18;
+    }();
+    dim3 grid(g.N, n), block(64);
+    if (slots == 13)
+        hipLaunchKernelGGL(k_me16<13>, grid, block, 0, stream, ref, curs, stride, g, mv, ns, cost);
+    else if (slots == 14)
+        hipLaunchKernelGGL(k_me16<14>, grid, block, 0, stream, ref, curs, stride, g, mv, ns, cost);
+    else
+        hipLaunchKernelGGL(k_me16<18>, grid, block, 0, stream, ref, curs, stride, g, mv, ns, cost);
     return 0;
 }
 
