@@ -38,6 +38,7 @@ struct vcs_ctx {
     size_t me_lds = 0;     // dynamic LDS of the generic ME kernel
     bool ref_valid = false;
     bool me_fast_ok = false;
+    int cus = 256;         // compute units of the device
     // single-frame buffers
     uint8_t *d_ref = nullptr, *d_cur = nullptr, *d_a = nullptr, *d_b = nullptr;
     int16_t *d_mv = nullptr;
@@ -172,7 +173,7 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     int rc = t_begin(c, VCS_T_ME, &ev);
     if (rc) return rc;
     if (c->me_fast_ok && !force_generic) {
-        rc = launch_me_fast(c->g, c->stream, ref, curs, stride, n, mv, ns, cost);
+        rc = launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, mv, ns, cost);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
     } else {
         switch (c->g.bs) {
@@ -400,6 +401,8 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
         }                                                                                  \
     } while (0)
     CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
+    if (c->cus < 1) c->cus = 1;
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipMalloc(&c->d_ref, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_cur, c->Fs));
