@@ -118,6 +118,9 @@ def main():
         if world > 1:
             dist.broadcast(t_ref, src=0)             # I frame over xGMI
             torch.cuda.current_stream().synchronize()
+        # every step is a new GOP: the per-reference work (k_me16's sum table) is
+        # redone inside the timed region, once per GOP as in a real encode
+        ctx.ref_written()
         ctx.gop_encode(0, n)                         # ME kernel + fused tail kernel
         if world > 1:
             ctx.sync()

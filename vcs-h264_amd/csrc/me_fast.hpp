@@ -9,31 +9,33 @@
 //     window's left edge j_min -- exactly the anchor of the candidate grid
 //     (motion.py:126,138).  Candidate cj then starts at byte 16*cj of a row:
 //     every candidate row is aligned ds_read_b128s, no byte shifting.
-//   * The current block is wave-uniform.  Its 16 rows are re-packed ONCE per
-//     block into the same 5-pixel-group format (negated, pad byte 0xFF), lane-
-//     parallel, and parked in 1 KB of LDS; the row loop reads them back with
-//     wave-uniform (broadcast) ds_read_b128.  The row loop therefore holds no
-//     scalar loads (SMEM shares lgkmcnt with LDS and would force full drains)
-//     and no re-packing: the vector ALU only sees v_lerp_u8 / v_and / v_bcnt /
-//     v_sad_u8.
 //   * Cost without a per-byte subtract.  (r - c) mod 256 = r - c + 256*[r < c],
 //     so  cost = sum(r) - sum(c) + 256 * #{r < c}.  #{r >= c} comes from bit 7
-//     of v_lerp_u8(r, ~c, 1) = (r - c + 256) >> 1 per byte (one v_and + one
-//     v_bcnt), sum(r) from v_sad_u8(r, 0); pad bytes carry ~c = 0xFF (always
-//     counted, subtracted as a constant) and r = 0.
+//     of v_lerp_u8(r, ~c, 1) = (r - c + 256) >> 1 per byte: one v_lerp_u8, one
+//     v_and, one v_bcnt per dword.  Pad bytes carry ~c = 0xFF (always counted,
+//     subtracted as a constant).
+//   * sum(r) does not depend on the current frame.  Every P frame of a GOP is
+//     searched against the same raw I frame (encoder.py:51-52), so the byte
+//     sum of each (block, candidate) reference patch is computed ONCE per
+//     reference frame (k_me16<.., kSums>, 100 x uint32 per block) and read
+//     back by the search: the row loop holds no v_sad_u8 at all.
+//   * The current block is wave-uniform.  Its 16 rows are re-packed once per
+//     block into the same 5-pixel-group format (negated, pad byte 0xFF), lane-
+//     parallel, parked in 1 KB of LDS and read back with wave-uniform
+//     (broadcast) ds_read_b128: no scalar loads in the row loop (SMEM shares
+//     lgkmcnt with LDS and would force full drains), no re-packing there.
 //   * LDS row pitch 18 slots of 16 B: with lane = 10*ci + cj the slot index is
 //     congruent to the lane index mod 16, which makes every ds_read_b128 lane
 //     group hit 16 distinct 16-byte slots (conflict-free; MI355X_MICROARCH.md
 //     LDS table).
-//   * 100 candidates = two passes of 64 lanes; both passes share each
-//     re-packed row of the current block.
+//   * 100 candidates = two passes of 64 lanes (64 + 36) over the same rows.
 //   * Persistent waves with register prefetch.  The kernel is bound by vector
-//     ALU issue (about 2,000 wave-instructions per block), and LDS limits it to
-//     two waves per SIMD, so nothing else may stall: each wave walks a strided
-//     list of blocks and issues ALL global loads of block i+1 (19 per lane,
-//     into registers) before it searches block i.  Work is dealt so that the
-//     blocks of one XCD are contiguous in the frame (reference-window reuse in
-//     that XCD's L2); the result never depends on the mapping.
+//     ALU issue and LDS admits only two waves per SIMD, so nothing else may
+//     stall: each wave walks a strided list of blocks and issues ALL global
+//     loads of block i+1 (into registers, "uniform base + 32-bit lane offset"
+//     form) before it searches block i.  Work is dealt so that the blocks of
+//     one XCD are contiguous in the frame (reference-window reuse in that
+//     XCD's L2); the result never depends on the mapping.
 #pragma once
 #include <stdlib.h>
 
@@ -41,8 +43,10 @@
 
 namespace vcs {
 
-constexpr int kMe16Rows = 64;    // 2 * win
-constexpr int kMe16Groups = 13;  // ceil(64 px / 5)
+constexpr int kMe16Rows = 64;        // 2 * win
+constexpr int kMe16Groups = 13;      // ceil(64 px / 5)
+constexpr int kMe16SumStride = 128;  // uint32 per block in the sum(r) table (100 used)
+enum { kMe16Search = 0, kMe16Sums = 1 };
 
 __device__ __forceinline__ uint4 load16_any_align(const uint8_t *p) {
     uint4 v;
@@ -71,55 +75,57 @@ __device__ __forceinline__ void me16_ld(Me16Q &Q, const void *p, bool keep4) {
     if (keep4) asm volatile("" ::"v"(Q.q3.y), "v"(Q.q3.z), "v"(Q.q3.w));
 }
 
-// 13 dwords of one candidate row against the re-packed current row.  Two
-// accumulator pairs keep the v_bcnt / v_sad_u8 chains short.
-__device__ __forceinline__ void me16_cost13(const uint4 &q0, const uint4 &q1, const uint4 &q2,
-                                            const uint4 &q3, const uint32_t (&nc)[13],
-                                            uint32_t (&cnt)[2], uint32_t (&sum)[2]) {
-    const uint32_t r[13] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                            q2.x, q2.y, q2.z, q2.w, q3.x & 0x00FFFFFFu};
+// #{r >= c} over the 13 dwords of one candidate row.  A dependent VALU
+// instruction issues ~1.7x later than an independent one on gfx950, so the
+// three steps are written as three passes over the 13 dwords (13 independent
+// v_lerp_u8, 13 independent v_and, then v_bcnt into 4 rotating accumulators)
+// and pinned in that order with a scheduling fence between the passes.
+// v_bcnt_u32_b32 is written with its accumulate operand (hipcc splits
+// popcount + add into bcnt(x, 0) and extra v_add3 otherwise).
+__device__ __forceinline__ void me16_count13(const Me16Q &a, const Me16Q &c, uint32_t (&cnt)[4]) {
+    const uint32_t r[13] = {a.q0.x, a.q0.y, a.q0.z, a.q0.w, a.q1.x, a.q1.y, a.q1.z,
+                            a.q1.w, a.q2.x, a.q2.y, a.q2.z, a.q2.w, a.q3.x};
+    const uint32_t nc[13] = {c.q0.x, c.q0.y, c.q0.z, c.q0.w, c.q1.x, c.q1.y, c.q1.z,
+                             c.q1.w, c.q2.x, c.q2.y, c.q2.z, c.q2.w, c.q3.x};
+    uint32_t t[13];
 #pragma unroll
-    for (int d = 0; d < 13; d++) {
-        uint32_t t = __builtin_amdgcn_lerp(r[d], nc[d], 0x01010101u) & 0x80808080u;
-        // v_bcnt_u32_b32 with its accumulate operand (hipcc splits popcount + add
-        // into bcnt(x, 0) and extra v_add3 otherwise)
-        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[d & 1]) : "v"(t));
-        sum[d & 1] = __builtin_amdgcn_sad_u8(r[d], 0u, sum[d & 1]);
-    }
+    for (int d = 0; d < 13; d++) t[d] = __builtin_amdgcn_lerp(r[d], nc[d], 0x01010101u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < 13; d++) t[d] &= 0x80808080u;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < 13; d++)
+        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[d & 3]) : "v"(t[d]));
+    __builtin_amdgcn_sched_barrier(0);
+}
+// Byte sum of the 13 dwords (the 13th holds 3 data bytes + one foreign byte).
+__device__ __forceinline__ void me16_sum13(const Me16Q &a, uint32_t (&sum)[4]) {
+    const uint32_t r[13] = {a.q0.x, a.q0.y, a.q0.z, a.q0.w, a.q1.x, a.q1.y, a.q1.z,
+                            a.q1.w, a.q2.x, a.q2.y, a.q2.z, a.q2.w, a.q3.x & 0x00FFFFFFu};
+#pragma unroll
+    for (int d = 0; d < 13; d++) sum[d & 3] = __builtin_amdgcn_sad_u8(r[d], 0u, sum[d & 3]);
 }
 
-// All 16 rows, software-pipelined one half-row ahead: while candidate set A of
-// row k is evaluated the reads of set B are in flight, and while B is
-// evaluated those of row k+1 (current row + set A) are -- with two waves per
-// SIMD nothing else would cover the LDS latency.  Live: <= 4 operand groups.
-template <bool TWO, int ROWB>
-__device__ __forceinline__ void me16_search(const uint32_t *s_cur, const uint8_t *p0,
-                                            const uint8_t *p1, uint32_t (&cnt0)[2],
-                                            uint32_t (&sum0)[2], uint32_t (&cnt1)[2],
-                                            uint32_t (&sum1)[2]) {
-    Me16Q c, a, b, cn, an;
-    me16_ld(c, s_cur, false);
-    me16_ld(a, p0, true);
-#pragma unroll
+// All 16 rows of two candidates per lane (p0: candidate `lane`, p1: candidate
+// `lane + 64`) against the same re-packed current rows.  MODE kSums: byte sums
+// instead of counts.
+template <int MODE, bool TWO, int ROWB>
+__device__ __forceinline__ void me16_rows(const uint32_t *s_cur, const uint8_t *p0,
+                                          const uint8_t *p1, uint32_t (&acc0)[4],
+                                          uint32_t (&acc1)[4]) {
+#pragma unroll 4
     for (int k = 0; k < 16; k++) {
+        Me16Q c, a, b;
+        if (MODE == kMe16Search) me16_ld(c, s_cur + k * 16, false);
+        me16_ld(a, p0 + k * ROWB, true);
         if (TWO) me16_ld(b, p1 + k * ROWB, true);
-        if (!TWO && k + 1 < 16) {
-            me16_ld(cn, s_cur + (k + 1) * 16, false);
-            me16_ld(an, p0 + (k + 1) * ROWB, true);
-        }
-        const uint32_t nc[13] = {c.q0.x, c.q0.y, c.q0.z, c.q0.w, c.q1.x, c.q1.y, c.q1.z,
-                                 c.q1.w, c.q2.x, c.q2.y, c.q2.z, c.q2.w, c.q3.x};
-        me16_cost13(a.q0, a.q1, a.q2, a.q3, nc, cnt0, sum0);
-        if (TWO) {
-            if (k + 1 < 16) {
-                me16_ld(cn, s_cur + (k + 1) * 16, false);
-                me16_ld(an, p0 + (k + 1) * ROWB, true);
-            }
-            me16_cost13(b.q0, b.q1, b.q2, b.q3, nc, cnt1, sum1);
-        }
-        if (k + 1 < 16) {
-            c = cn;
-            a = an;
+        if (MODE == kMe16Search) {
+            me16_count13(a, c, acc0);
+            if (TWO) me16_count13(b, c, acc1);
+        } else {
+            me16_sum13(a, acc0);
+            if (TWO) me16_sum13(b, acc1);
         }
     }
 }
@@ -129,53 +135,84 @@ struct Me16Regs {
     uint32_t rv[3], cv[3];   // co-located ref / cur block, 3 dwords per lane
     uint4 stg[kMe16Groups];  // search window, 13 x 16 bytes per lane
     uint32_t cq[4];          // current block in 5-pixel-group order, 208 dwords / 64 lanes
+    uint32_t sr[2];          // sum(r) of candidates lane and lane + 64 (from the table)
 };
-
-// Issues the loads of work item `w` (= frame * N + block).  No branches: a
-// conditional load would make hipcc wait for it on the spot.
-__device__ __forceinline__ void me16_issue(const uint8_t *__restrict__ ref,
-                                           const uint8_t *__restrict__ curs, size_t cur_stride,
-                                           const Geom &g, int w, int lane, Me16Regs &R) {
-    constexpr int BS = 16, WIN = 32;
-    const int f = w / g.N, blk = w - f * g.N;
-    const int byi = blk / g.nbx, bxi = blk - byi * g.nbx;
-    const int x = bxi * BS, y = byi * BS;
-    const uint8_t *__restrict__ cur = curs + (size_t)f * cur_stride;
-    const size_t blk_off = (size_t)y * g.pitch + (size_t)(48 * bxi);
+// Per-lane byte offsets of those loads relative to wave-uniform bases.  They do
+// not depend on the block, so they are computed once per wave; every load is
+// then "uniform 64-bit base + 32-bit lane offset" (saddr form): no per-block
+// address arithmetic and no 64-bit address registers.
+struct Me16Offs {
+    uint32_t blk[3];
+    uint32_t stg[kMe16Groups];
+    uint32_t cq[4];
+};
+__device__ __forceinline__ void me16_offsets(const Geom &g, int lane, Me16Offs &O) {
 #pragma unroll
     for (int t = 0; t < 3; t++) {
         const int idx = lane + 64 * t, row = idx / 12, col = idx - row * 12;
-        const size_t off = blk_off + (size_t)row * g.pitch + (size_t)(4 * col);
-        R.rv[t] = *(const uint32_t *)(ref + off);
-        R.cv[t] = *(const uint32_t *)(cur + off);
+        O.blk[t] = (uint32_t)(row * g.pitch + 4 * col);
     }
-    const int i_min = max(y - WIN, 0), j_min = max(x - WIN, 0);
-    const int wrows = min(y + WIN, g.H) - i_min;
-    const uint8_t *__restrict__ wsrc = ref + (size_t)i_min * g.pitch + (size_t)(3 * j_min);
 #pragma unroll
     for (int t = 0; t < kMe16Groups; t++) {
         const int e = lane + 64 * t, row = e / kMe16Groups, gi = e - row * kMe16Groups;
-        const int rc = min(row, wrows - 1);  // rows past a clipped window: clamped, never read
-        R.stg[t] = load16_any_align(wsrc + (size_t)rc * g.pitch + (size_t)(15 * gi));
+        O.stg[t] = (uint32_t)(row * g.pitch + 15 * gi);
     }
     // current block, dword j of row `row` in 5-pixel-group order starts at byte
     // 15*(j/4) + 4*(j%4) of the row (j = 12: byte 45); unaligned dword loads
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int e = min(lane + 64 * t, 16 * 13 - 1), row = e / 13, j = e - row * 13;
-        const int boff = j == 12 ? 45 : 15 * (j >> 2) + 4 * (j & 3);
-        uint32_t v;
-        __builtin_memcpy(&v, cur + blk_off + (size_t)row * g.pitch + (size_t)boff, 4);
-        R.cq[t] = v;
+        O.cq[t] = (uint32_t)(row * g.pitch + (j == 12 ? 45 : 15 * (j >> 2) + 4 * (j & 3)));
     }
 }
 
-// SLOTS: 16-byte slots per LDS window row (18 = conflict-free, 13/14 = denser).
-template <int SLOTS>
+// Issues the loads of work item `w` (= frame * N + block).  No branches (a
+// conditional load would make hipcc wait for it on the spot) and no clamping:
+// the window is always fetched 64 rows deep; for blocks near the bottom edge
+// the extra rows lie in the slack behind the reference frame (the context
+// allocates it) and are never used.
+template <int MODE>
+__device__ __forceinline__ void me16_issue(const uint8_t *__restrict__ ref,
+                                           const uint8_t *__restrict__ curs, size_t cur_stride,
+                                           const uint32_t *__restrict__ sums, const Geom &g, int w,
+                                           int lane, const Me16Offs &O, Me16Regs &R) {
+    constexpr int BS = 16, WIN = 32;
+    const int f = w / g.N, blk = w - f * g.N;
+    const int byi = blk / g.nbx, bxi = blk - byi * g.nbx;
+    const int x = bxi * BS, y = byi * BS;
+    const size_t blk_off = (size_t)y * g.pitch + (size_t)(48 * bxi);
+    const int i_min = max(y - WIN, 0), j_min = max(x - WIN, 0);
+    const uint8_t *__restrict__ wsrc = ref + (size_t)i_min * g.pitch + (size_t)(3 * j_min);
+    if (MODE == kMe16Search) {
+        const uint8_t *__restrict__ cblk = curs + (size_t)f * cur_stride + blk_off;  // uniform
+        const uint8_t *__restrict__ rblk = ref + blk_off;                             // uniform
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            R.rv[t] = *(const uint32_t *)(rblk + O.blk[t]);
+            R.cv[t] = *(const uint32_t *)(cblk + O.blk[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            uint32_t v;
+            __builtin_memcpy(&v, cblk + O.cq[t], 4);
+            R.cq[t] = v;
+        }
+        const uint32_t *__restrict__ sb = sums + (size_t)blk * kMe16SumStride;  // uniform
+        R.sr[0] = sb[lane];
+        R.sr[1] = sb[lane + 64];
+    }
+#pragma unroll
+    for (int t = 0; t < kMe16Groups; t++) R.stg[t] = load16_any_align(wsrc + O.stg[t]);
+}
+
+// MODE kMe16Search: motion search of `total` work items (frame-major blocks).
+// MODE kMe16Sums:   fills sums[blk * 128 + cand] for the N blocks of `ref`.
+// SLOTS: 16-byte slots per LDS window row (18 = conflict-free, 14 = denser).
+template <int SLOTS, int MODE>
 __global__ __launch_bounds__(64, 2) void k_me16(
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
-    Geom g, int total, int16_t *__restrict__ mv, uint32_t *__restrict__ n_static,
-    unsigned long long *__restrict__ cost_out) {
+    Geom g, int total, uint32_t *__restrict__ sums, int16_t *__restrict__ mv,
+    uint32_t *__restrict__ n_static, unsigned long long *__restrict__ cost_out) {
     constexpr int kRowB = SLOTS * 16;
     // one array: [window 64 rows x kRowB][current block 16 rows x 64 B]
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe16Rows * kRowB + 16 * 64];
@@ -192,14 +229,16 @@ __global__ __launch_bounds__(64, 2) void k_me16(
     int w = xcd * chunk + wi;
     if (w >= w_end) return;
 
+    Me16Offs O;
+    me16_offsets(g, lane, O);
     Me16Regs A;
-    me16_issue(ref, curs, cur_stride, g, w, lane, A);
+    me16_issue<MODE>(ref, curs, cur_stride, sums, g, w, lane, O, A);
 
     for (;;) {
         // ---- prefetch the next block of this wave while this one is searched ------
         const int wn = w + nw;
         Me16Regs B;
-        me16_issue(ref, curs, cur_stride, g, min(wn, w_end - 1), lane, B);
+        me16_issue<MODE>(ref, curs, cur_stride, sums, g, min(wn, w_end - 1), lane, O, B);
 
         const int f = w / g.N, blk = w - f * g.N;
         const int byi = blk / g.nbx, bxi = blk - byi * g.nbx;
@@ -208,39 +247,45 @@ __global__ __launch_bounds__(64, 2) void k_me16(
 
         // ---- static test (motion.py:109-116): sum(max(r - c, 0)) -------------------
         //   max(r - c, 0) = (|r - c| + r - c) / 2 per byte -> three v_sad_u8 per dword
-        uint32_t s_abs = 0, s_r = 0, s_c = 0;
+        bool is_static = false;
+        uint32_t s_c = 0;
+        if (MODE == kMe16Search) {
+            uint32_t s_abs = 0, s_r = 0;
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            s_abs = __builtin_amdgcn_sad_u8(A.rv[t], A.cv[t], s_abs);
-            s_r = __builtin_amdgcn_sad_u8(A.rv[t], 0u, s_r);
-            s_c = __builtin_amdgcn_sad_u8(A.cv[t], 0u, s_c);
-        }
-        s_abs = wave_sum_u32(s_abs);
-        s_r = wave_sum_u32(s_r);
-        s_c = wave_sum_u32(s_c);  // sum of the current block's bytes
-        const uint32_t sdiff = (s_abs + s_r - s_c) >> 1;
-        if (!g.never_static && sdiff <= g.thresh) {
-            if (lane == 0) {
+            for (int t = 0; t < 3; t++) {
+                s_abs = __builtin_amdgcn_sad_u8(A.rv[t], A.cv[t], s_abs);
+                s_r = __builtin_amdgcn_sad_u8(A.rv[t], 0u, s_r);
+                s_c = __builtin_amdgcn_sad_u8(A.cv[t], 0u, s_c);
+            }
+            s_abs = wave_sum_u32(s_abs);
+            s_r = wave_sum_u32(s_r);
+            s_c = wave_sum_u32(s_c);  // sum of the current block's bytes
+            const uint32_t sdiff = (s_abs + s_r - s_c) >> 1;
+            is_static = !g.never_static && sdiff <= g.thresh;
+            if (is_static && lane == 0) {
                 mv[2 * oidx + 0] = 0;
                 mv[2 * oidx + 1] = 0;
                 atomicAdd(&n_static[f], 1u);
                 if (cost_out) cost_out[oidx] = sdiff;
             }
-        } else {
+        }
+        if (!is_static) {
             // ---- park the window in 5-pixel groups (motion.py:125-129) -------------
 #pragma unroll
             for (int t = 0; t < kMe16Groups; t++) {
                 const int e = lane + 64 * t, row = e / kMe16Groups, gi = e - row * kMe16Groups;
                 uint4 v = A.stg[t];
-                v.w &= 0x00FFFFFFu;  // pad byte = 0 so that it adds nothing to sum(r)
+                v.w &= 0x00FFFFFFu;  // pad byte = 0
                 *(uint4 *)(s_win + row * kRowB + gi * 16) = v;
             }
             // ... and the negated current block next to it (pad byte -> 0xFF)
+            if (MODE == kMe16Search) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int e = lane + 64 * t, row = e / 13, j = e - row * 13;
-                const uint32_t padm = ((j & 3) == 3 || j == 12) ? 0xFF000000u : 0u;
-                if (e < 16 * 13) s_cur[row * 16 + j] = ~A.cq[t] | padm;
+                for (int t = 0; t < 4; t++) {
+                    const int e = lane + 64 * t, row = e / 13, j = e - row * 13;
+                    const uint32_t padm = ((j & 3) == 3 || j == 12) ? 0xFF000000u : 0u;
+                    if (e < 16 * 13) s_cur[row * 16 + j] = ~A.cq[t] | padm;
+                }
             }
             __syncthreads();
 
@@ -253,45 +298,49 @@ __global__ __launch_bounds__(64, 2) void k_me16(
             const int ncand = nci * ncj;  // <= 100
             const int cand0 = lane, cand1 = lane + 64;
             const bool act0 = cand0 < ncand, act1 = cand1 < ncand;
-            const bool two = ncand > 64;  // wave-uniform
             int ci0 = 0, cj0 = 0, ci1 = 0, cj1 = 0;
             if (act0) { ci0 = cand0 / ncj; cj0 = cand0 - ci0 * ncj; }
             if (act1) { ci1 = cand1 / ncj; cj1 = cand1 - ci1 * ncj; }
             const uint8_t *p0 = s_win + (STEP * ci0) * kRowB + cj0 * 16;
             const uint8_t *p1 = s_win + (STEP * ci1) * kRowB + cj1 * 16;
 
-            uint32_t cnt0[2] = {0, 0}, sum0[2] = {0, 0}, cnt1[2] = {0, 0}, sum1[2] = {0, 0};
-            if (two)  // wave-uniform
-                me16_search<true, kRowB>(s_cur, p0, p1, cnt0, sum0, cnt1, sum1);
+            uint32_t acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+            if (ncand > 64)  // wave-uniform
+                me16_rows<MODE, true, kRowB>(s_cur, p0, p1, acc0, acc1);
             else
-                me16_search<false, kRowB>(s_cur, p0, p1, cnt0, sum0, cnt1, sum1);
-            const uint32_t cnt0s = cnt0[0] + cnt0[1], cnt1s = cnt1[0] + cnt1[1];
-            const uint32_t sum0s = sum0[0] + sum0[1], sum1s = sum1[0] + sum1[1];
-            // cost = sum(r) - sum(c) + 256 * #{r < c}; 64 pad bytes were always counted
-            const uint32_t n_lt0 = 768u + 64u - cnt0s, n_lt1 = 768u + 64u - cnt1s;
-            const uint32_t cost0 = sum0s + 256u * n_lt0 - s_c;
-            const uint32_t cost1 = sum1s + 256u * n_lt1 - s_c;
-            uint32_t key = 0xFFFFFFFFu;  // (cost << 7) | raster index: motion.py:149 order
-            if (act0) key = (cost0 << 7) | (uint32_t)cand0;
-            if (act1) key = min(key, (cost1 << 7) | (uint32_t)cand1);
-            key = wave_min_u32(key);
+                me16_rows<MODE, false, kRowB>(s_cur, p0, p1, acc0, acc1);
 
-            if (lane == 0) {
-                int bx = 0, by = 0;                    // motion.py:102
-                unsigned long long c = 9999999999ull;  // motion.py:120
-                if (key != 0xFFFFFFFFu) {
-                    const int cand = (int)(key & 127u);
-                    by = i_min + (cand / ncj) * STEP;
-                    bx = j_min + (cand % ncj) * STEP;
-                    c = key >> 7;
+            if (MODE == kMe16Sums) {
+                uint32_t *__restrict__ sb = sums + (size_t)blk * kMe16SumStride;
+                sb[cand0] = act0 ? acc0[0] + acc0[1] + acc0[2] + acc0[3] : 0u;
+                sb[cand1] = act1 ? acc1[0] + acc1[1] + acc1[2] + acc1[3] : 0u;
+            } else {
+                // cost = sum(r) - sum(c) + 256 * #{r < c}; 64 pad bytes always counted
+                const uint32_t n_lt0 = 768u + 64u - (acc0[0] + acc0[1] + acc0[2] + acc0[3]);
+                const uint32_t n_lt1 = 768u + 64u - (acc1[0] + acc1[1] + acc1[2] + acc1[3]);
+                const uint32_t cost0 = A.sr[0] + 256u * n_lt0 - s_c;
+                const uint32_t cost1 = A.sr[1] + 256u * n_lt1 - s_c;
+                uint32_t key = 0xFFFFFFFFu;  // (cost << 7) | raster index: motion.py:149
+                if (act0) key = (cost0 << 7) | (uint32_t)cand0;
+                if (act1) key = min(key, (cost1 << 7) | (uint32_t)cand1);
+                key = wave_min_u32(key);
+                if (lane == 0) {
+                    int bx = 0, by = 0;                    // motion.py:102
+                    unsigned long long c = 9999999999ull;  // motion.py:120
+                    if (key != 0xFFFFFFFFu) {
+                        const int cb = (int)(key & 127u);
+                        by = i_min + (cb / ncj) * STEP;
+                        bx = j_min + (cb % ncj) * STEP;
+                        c = key >> 7;
+                    }
+                    mv[2 * oidx + 0] = (int16_t)(bx - x);
+                    mv[2 * oidx + 1] = (int16_t)(by - y);
+                    if (cost_out) cost_out[oidx] = c;
                 }
-                mv[2 * oidx + 0] = (int16_t)(bx - x);
-                mv[2 * oidx + 1] = (int16_t)(by - y);
-                if (cost_out) cost_out[oidx] = c;
             }
             __syncthreads();  // the window is rewritten by the next block
         }
-        if (wn >= w_end) break;  // wave-uniform; every wave leaves after <= its share
+        if (wn >= w_end) break;  // wave-uniform; every wave leaves after its share
         w = wn;
         A = B;
     }
@@ -302,33 +351,61 @@ __global__ __launch_bounds__(64, 2) void k_me16(
 inline bool me_fast_supported(const Geom &g) {
     return g.bs == 16 && g.win == 32 && g.step == 5 && (g.W % 4) == 0 && g.N > 0;
 }
+// Bytes of slack the reference frame needs behind it (window rows fetched
+// without clamping at the bottom edge) and of the per-reference sum(r) table.
+inline size_t me_fast_ref_slack(const Geom &g) { return (size_t)(kMe16Rows + 2) * g.pitch; }
+inline size_t me_fast_sums_bytes(const Geom &g) {
+    return (size_t)(g.N > 0 ? g.N : 1) * kMe16SumStride * sizeof(uint32_t);
+}
 
-// n frames of g.N blocks each; `cus` = compute units of the device.  mv / cost
-// are indexed frame-major, i.e. by work item.
-inline int launch_me_fast(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
-                          const uint8_t *curs, size_t stride, int n, int16_t *mv, uint32_t *ns,
-                          unsigned long long *cost) {
+inline int me16_slots() {
     static const int slots = [] {
         const char *e = getenv("VCS_ME16_SLOTS");  // tuning knob: 14 or 18
-        int v = e ? atoi(e) : 18;
-        return v == 14 ? v : 18;
+        return (e && atoi(e) == 14) ? 14 : 18;
     }();
+    return slots;
+}
+inline int me16_grid(int cus, long long total) {
     static const int per_cu = [] {
         const char *e = getenv("VCS_ME16_WAVES_PER_CU");  // tuning knob
         int v = e ? atoi(e) : 8;
         return v >= 1 && v <= 32 ? v : 8;
     }();
+    long long grid = (long long)cus * per_cu;  // resident waves: LDS admits 8 per CU
+    grid = (grid + 7) / 8 * 8;                 // a multiple of the XCD count
+    const long long cap = (total + 7) / 8 * 8;
+    return (int)(grid > cap ? cap : grid);
+}
+
+// sum(r) table of `ref` (once per reference frame).
+inline int launch_me_fast_sums(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
+                               uint32_t *sums) {
+    dim3 gd(me16_grid(cus, g.N)), block(64);
+    if (me16_slots() == 14)
+        hipLaunchKernelGGL((k_me16<14, kMe16Sums>), gd, block, 0, stream, ref, ref, (size_t)0, g,
+                           g.N, sums, (int16_t *)nullptr, (uint32_t *)nullptr,
+                           (unsigned long long *)nullptr);
+    else
+        hipLaunchKernelGGL((k_me16<18, kMe16Sums>), gd, block, 0, stream, ref, ref, (size_t)0, g,
+                           g.N, sums, (int16_t *)nullptr, (uint32_t *)nullptr,
+                           (unsigned long long *)nullptr);
+    return 0;
+}
+
+// n frames of g.N blocks each; `cus` = compute units of the device.  mv / cost
+// are indexed frame-major, i.e. by work item.  `sums` must hold ref's table.
+inline int launch_me_fast(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
+                          const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
+                          uint32_t *ns, unsigned long long *cost) {
     const long long total = (long long)g.N * n;
     if (total > 0x7FFFFFFF) return -1;
-    int grid = cus * per_cu;            // resident waves: LDS admits 8 (18 slots) per CU
-    grid = (grid + 7) / 8 * 8;          // a multiple of the XCD count
-    if ((long long)grid > (total + 7) / 8 * 8) grid = (int)((total + 7) / 8 * 8);
-    dim3 gd(grid), block(64);
-    const int tot = (int)total;
-    if (slots == 14)
-        hipLaunchKernelGGL(k_me16<14>, gd, block, 0, stream, ref, curs, stride, g, tot, mv, ns, cost);
+    dim3 gd(me16_grid(cus, total)), block(64);
+    if (me16_slots() == 14)
+        hipLaunchKernelGGL((k_me16<14, kMe16Search>), gd, block, 0, stream, ref, curs, stride, g,
+                           (int)total, sums, mv, ns, cost);
     else
-        hipLaunchKernelGGL(k_me16<18>, gd, block, 0, stream, ref, curs, stride, g, tot, mv, ns, cost);
+        hipLaunchKernelGGL((k_me16<18, kMe16Search>), gd, block, 0, stream, ref, curs, stride, g,
+                           (int)total, sums, mv, ns, cost);
     return 0;
 }
 

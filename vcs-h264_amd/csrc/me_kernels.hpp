@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void k_me_generic(
     const int nci = ri >= 1 ? (ri - 1) / g.step + 1 : 0;
     const int ncj = rj >= 1 ? (rj - 1) / g.step + 1 : 0;
     const int ncand = nci * ncj;
-    const uint32_t tailmask = (rowb & 3) ? (0xFFFFFFFFu >> (8 * (4 - (rowb & 3)))) : 0xFFFFFFFFu;
+    const uint32_t tailmask = 0xFFFFFFFFu >> ((8 * (4 - (rowb & 3))) & 31);  // rowb % 4 == 0: all
 
     constexpr int UR_ROWS = BS_T ? BS_T : 1, UR_DW = BS_T ? (3 * BS_T + 3) / 4 : 1;
     unsigned long long best = ~0ull;

@@ -38,6 +38,8 @@ struct vcs_ctx {
     size_t me_lds = 0;     // dynamic LDS of the generic ME kernel
     bool ref_valid = false;
     bool me_fast_ok = false;
+    uint32_t *d_sums = nullptr;  // k_me16: per-reference sum(r) table
+    bool sums_valid = false;
     int cus = 256;         // compute units of the device
     // single-frame buffers
     uint8_t *d_ref = nullptr, *d_cur = nullptr, *d_a = nullptr, *d_b = nullptr;
@@ -173,7 +175,12 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     int rc = t_begin(c, VCS_T_ME, &ev);
     if (rc) return rc;
     if (c->me_fast_ok && !force_generic) {
-        rc = launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, mv, ns, cost);
+        if (!c->sums_valid) {  // once per reference frame (all P frames of a GOP share it)
+            launch_me_fast_sums(c->g, c->stream, c->cus, ref, c->d_sums);
+            HIP_TRY(c, hipGetLastError());
+            c->sums_valid = true;
+        }
+        rc = launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
     } else {
         switch (c->g.bs) {
@@ -404,7 +411,11 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     CREATE_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
     if (c->cus < 1) c->cus = 1;
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipMalloc(&c->d_ref, c->Fs));
+    // the reference carries slack rows: k_me16 fetches its window 64 rows deep
+    // without clamping at the bottom edge (the extra rows are never used)
+    CREATE_TRY(hipMalloc(&c->d_ref, c->Fs + me_fast_ref_slack(g)));
+    CREATE_TRY(hipMemset(c->d_ref, 0, c->Fs + me_fast_ref_slack(g)));
+    CREATE_TRY(hipMalloc(&c->d_sums, me_fast_sums_bytes(g)));
     CREATE_TRY(hipMalloc(&c->d_cur, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_a, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_b, c->Fs));
@@ -439,6 +450,7 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     hipFree(c->d_ref); hipFree(c->d_cur); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_mv);
     hipFree(c->d_coords); hipFree(c->d_cost); hipFree(c->d_ns); hipFree(c->d_planes);
     hipFree(c->d_DQ);
+    hipFree(c->d_sums);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return VCS_OK;
@@ -484,6 +496,7 @@ int vcs_set_ref(vcs_ctx *c, const uint8_t *ref) {
     HIP_TRY(c, hipMemcpyAsync(c->d_ref, ref, c->F, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->ref_valid = true;
+    c->sums_valid = false;
     return VCS_OK;
 }
 
@@ -753,6 +766,7 @@ int vcs_ref_written(vcs_ctx *c) {
     int rc = use(c);
     if (rc) return rc;
     c->ref_valid = true;
+    c->sums_valid = false;
     return VCS_OK;
 }
 
