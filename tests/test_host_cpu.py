@@ -1,0 +1,121 @@
+"""Host-side checks that need no GPU: the C ABI library loads and exports every
+symbol include/vcs_hip.h declares, host-only entry points agree with the golden
+vectors, the drop-in modules mirror the reference's interface, and the product
+path fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+
+
+@pytest.fixture(scope="module")
+def vh():
+    import vcs_hip
+    if not os.path.exists(vcs_hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    vcs_hip.load()
+    return vcs_hip
+
+
+def header_symbols():
+    src = open(os.path.join(REPO, "include", "vcs_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vcs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(vh):
+    syms = header_symbols()
+    assert len(syms) >= 30
+    lib = ctypes.CDLL(vh.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), "libvcs_hip.so does not export %s" % s
+        assert s in vh.SIGNATURES, "vcs_hip.py has no prototype for %s" % s
+    assert sorted(vh.SIGNATURES) == syms
+    assert vh.load().vcs_abi_version() == 1
+
+
+def test_host_only_entry_points_match_golden(vh):
+    g = load_golden("dct_small.npz")
+    assert np.array_equal(vh.dct_matrix(), g["dctmat"])  # DCTcompressor.py:124-133
+    for qf in (10, 50, 99):
+        assert np.array_equal(vh.make_q(float(qf)), g["Q_q%d" % qf])  # :29-38
+    with pytest.raises(ValueError):
+        vh.make_q(100.0)
+    with pytest.raises(ValueError):
+        vh.make_q(0.0) if False else vh.make_q(150.0)
+
+
+def test_no_cpu_fallback(vh):
+    if vh.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(vh.VcsError) as e:
+        vh.Context(64, 64, 16)
+    assert "no usable HIP device" in str(e.value) and "no CPU fallback" in str(e.value)
+    # nothing in the product tree may import the oracle
+    pkg = os.path.join(REPO, "vcs-h264_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "liboracle" not in txt and "from oracle" not in txt and \
+                    "import oracle" not in txt, f
+
+
+def test_dropin_interface_mirrors_reference(vh, capsys):
+    import DCTcompressor as C
+    import decoder as D
+    import encoder as E
+    import frame as F
+    import motion as M
+    # module-level names the reference exposes (motion.py:8-11, DCTcompressor.py:7-38)
+    assert M.SIMILARITY_THRESHOLD == 2000 and M.CHANNELS == 3 and M.WRITE_STATIC_BLOCK is True
+    assert C.QF == 50.0 and C.QY.shape == (8, 8) and C.QC.shape == (8, 8) and len(C.Q) == 3
+    assert C.QY[1, 5] == 48 and C.QC[0, 0] == 17
+    mp = M.MotionProcessor(16, [48, 64])
+    assert (mp.block_size, mp.search_window_size, mp.shape) == (16, 32, [48, 64])
+    for name in ("process_motion_prediction", "get_residuals", "reconstruct_from_motion_vectors"):
+        assert callable(getattr(mp, name))
+    c = C.DCTCompressor(8)
+    assert c.blocksize == 8 and c.compressed == [] and c.Q is C.Q
+    f = F.Frame("P", motion_vectors=[[0, 0]], residuals=None, block_coords=[[0, 0]], index=3,
+                ref_idx=1)
+    assert (f.t, f.mv, f.r, f.c, f.i, f.ref_i) == ("P", [[0, 0]], None, [[0, 0]], 3, 1)
+    # block grid: raster order, [x, y] entries, full blocks only (motion.py:74-98)
+    co = M.MotionProcessor(16, [50, 70])._block_coords().tolist()
+    assert co == [[0, 0], [16, 0], [32, 0], [48, 0], [0, 16], [16, 16], [32, 16], [48, 16],
+                  [0, 32], [16, 32], [32, 32], [48, 32]]
+    # I frames never touch the GPU: they alias the caller's array (encoder.py:41-43)
+    enc = E.Encoder(pattern=["I", "P", "P", "P"], shape=[48, 64], block_size=8, with_DCT=True)
+    img = np.zeros((48, 64, 3), np.uint8)
+    enc.encode_frame(img, 0)
+    enc.encode_frame(img, 4)
+    assert [fr.t for fr in enc.encoded_frames] == ["I", "I"] and enc.ref_frames[0] is img
+    assert enc.ENCODING_PATTERN_LENGTH == 4
+    if vh.device_count() == 0:  # a P frame needs the GPU and must say so
+        with pytest.raises(vh.VcsError):
+            enc.encode_frame(img, 1)
+    dec = D.Decoder(encoded_frames=enc.encoded_frames, fps=25.0, shape=[48, 64],
+                    ref_frames=enc.ref_frames, block_size=8, with_DCT=True, sink=[].append)
+    dec.reconstruct_video(with_residuals=True)
+    with pytest.raises(ValueError):  # block_size != 8 with DCT fails as in the reference
+        C.DCTCompressor(16).compress(np.zeros((48, 64, 3), np.uint8))
+    with pytest.raises(NotImplementedError):
+        C.DCTCompressor(8).compress(np.zeros((50, 70, 3), np.uint8))
+    capsys.readouterr()
+
+
+def test_synth_is_deterministic():
+    from synth import synth_gop, synth_static, synth_v1
+    a = synth_v1(48, 64, seed=5)
+    b = synth_v1(48, 64, seed=5)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    ref, fr = synth_gop(48, 64, 4, seed=5)
+    ref2, fr2 = synth_gop(48, 64, 2, seed=5, first=3)
+    assert np.array_equal(ref, ref2) and np.array_equal(fr[2:], fr2)
+    r, c = synth_static(64, 64, seed=1, bs=16, frac=0.5)
+    assert r.shape == c.shape == (64, 64, 3)
