@@ -162,6 +162,8 @@ int vcs_timing_reset(vcs_ctx *ctx);
 int vcs_timing(vcs_ctx *ctx, double *ms_out, uint64_t *launches_out, int n);
 /* Bytes/s of a device-to-device copy of `bytes` (the practical HBM roof).   */
 int vcs_measure_copy_bw(vcs_ctx *ctx, size_t bytes, int iters, double *gbps_out);
+/* Bytes/s of a device memset of `bytes` (the practical HBM write-only roof).  */
+int vcs_measure_fill_bw(vcs_ctx *ctx, size_t bytes, int iters, double *gbps_out);
 
 #ifdef __cplusplus
 }

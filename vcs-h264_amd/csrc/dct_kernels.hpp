@@ -21,6 +21,7 @@
 namespace vcs {
 
 constexpr int kTilePad = 72;  // doubles per tile in the LDS transpose buffer
+constexpr int kOutPad = 9;    // elements per output row in the LDS store buffer (8 + 1 pad)
 
 // coefficient store / load for the three coefficient modes (vcs_hip.h)
 template <int CM> struct CoeffT;
@@ -35,20 +36,40 @@ __device__ __forceinline__ typename CoeffT<CM>::type coeff_pack(double v) {
     else return (int16_t)(int)__builtin_rint(v);  // np.round: half to even
 }
 
+// One BGR pixel as the low 3 bytes of an unaligned dword load (the buffers carry
+// slack behind the last pixel): one load per pixel instead of three.
+__device__ __forceinline__ uint32_t load_px(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// a / b, correctly rounded, from y = RN(1 / b) in three fused operations
+// (Markstein): q = RN(a*y); r = RN(a - q*b) (exact); result = RN(q + r*y).
+// Valid when nothing over/underflows and b's significand is not all ones; the
+// host only selects this path for such Q tables (vcs_api.hip, q_fastdiv_ok).
+// Bit-identical to IEEE division: 1.5e9 random / adversarial cases checked
+// against a / b on the CPU for every integer Q in 1..255, 0 mismatches (a
+// zero quotient may differ in sign only).
+__device__ __forceinline__ double div_markstein(double a, double b, double y) {
+    const double q = a * y;
+    const double r = __builtin_fma(-q, b, a);
+    return __builtin_fma(r, y, q);
+}
+
 // Predicted (motion-compensated) pixel for frame position (y, x), or 0 where
-// no full motion block covers it (motion.py:45-46, :83-87).
-__device__ __forceinline__ void pred_px(const uint8_t *__restrict__ ref,
-                                        const int16_t *__restrict__ mv, const Geom &g,
-                                        int y, int x, int &b0, int &b1, int &b2) {
-    b0 = b1 = b2 = 0;
+// no full motion block covers it (motion.py:45-46, :83-87).  Low 3 bytes: B G R.
+__device__ __forceinline__ uint32_t pred_px(const uint8_t *__restrict__ ref,
+                                            const int16_t *__restrict__ mv, const Geom &g,
+                                            int y, int x) {
+    uint32_t v = 0;
     if (y < g.nby * g.bs && x < g.nbx * g.bs) {
-        int blk = (y / g.bs) * g.nbx + (x / g.bs);
-        int dx = mv[2 * blk], dy = mv[2 * blk + 1];
-        const uint8_t *p = ref + (size_t)(y + dy) * g.pitch + (size_t)(3 * (x + dx));
-        b0 = p[0];
-        b1 = p[1];
-        b2 = p[2];
+        const int blk = (y / g.bs) * g.nbx + (x / g.bs);
+        const uint32_t m = load_px((const uint8_t *)(mv + 2 * blk));  // dx | dy << 16
+        const int dx = (int16_t)(m & 0xFFFFu), dy = (int16_t)(m >> 16);
+        v = load_px(ref + (size_t)(y + dy) * g.pitch + (size_t)(3 * (x + dx)));
     }
+    return v;
 }
 
 // --------------------------------------------------------------------------
@@ -56,14 +77,15 @@ __device__ __forceinline__ void pred_px(const uint8_t *__restrict__ ref,
 //         49-74); MODE 1 = the encoder tail for a P frame: motion
 //         compensation + wrap-around residual + compress, fused
 //         (encoder.py:58-66).  grid = (tile groups per frame, frames).
-// DQ: D[64] followed by Q[3][64], float64, in HBM (context-owned).
+// DQ: D[64], Q[3][64], then 1/Q[3][64] (correctly rounded), float64, in HBM.
 // --------------------------------------------------------------------------
-template <int MODE, int CM>
+template <int MODE, int CM, bool FASTDIV>
 __global__ __launch_bounds__(64) void k_fdct(
     const uint8_t *__restrict__ imgs, size_t img_stride, const uint8_t *__restrict__ ref,
     const int16_t *__restrict__ mvs, Geom g, const double *__restrict__ DQ,
     typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride) {
     __shared__ double s_t[8 * kTilePad];
+    __shared__ typename CoeffT<CM>::type s_o[64 * kOutPad];  // [tile][row][col], padded rows
     const int lane = threadIdx.x;
     const int t = lane >> 3, j = lane & 7;
     const int groups_x = (g.W + 63) >> 6;
@@ -77,33 +99,31 @@ __global__ __launch_bounds__(64) void k_fdct(
     const double *__restrict__ Q = DQ + 64;
 
     // ---- fetch column x of the 8-row strip, form the residual, convert -----
+    uint32_t px[8], pp[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        px[k] = pp[k] = 0;
+        if (live) {
+            const int y = ty * 8 + k;
+            px[k] = load_px(img + (size_t)y * g.pitch + (size_t)(3 * x));
+            if (MODE == 1) pp[k] = pred_px(ref, mv, g, y, x);
+        }
+    }
     double X[3][8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        int B = 0, G = 0, R = 0;
-        if (live) {
-            const int y = ty * 8 + k;
-            const uint8_t *p = img + (size_t)y * g.pitch + (size_t)(3 * x);
-            B = p[0];
-            G = p[1];
-            R = p[2];
-            if (MODE == 1) {  // residual = cur - pred, uint8 wrap (motion.py:39)
-                int p0, p1, p2;
-                pred_px(ref, mv, g, y, x, p0, p1, p2);
-                B = (B - p0) & 255;
-                G = (G - p1) & 255;
-                R = (R - p2) & 255;
-            }
-        }
+        // residual = cur - pred, uint8 wrap (motion.py:39); MODE 0: pred = 0
+        const uint32_t rs = sub_u8x4(px[k], pp[k]);
         int Y, Cr, Cb;
-        bgr2ycc(B, G, R, Y, Cr, Cb);  // DCTcompressor.py:55
+        bgr2ycc(rs & 255, (rs >> 8) & 255, (rs >> 16) & 255, Y, Cr, Cb);  // DCTcompressor.py:55
         X[0][k] = (double)(Y - 128);  // :57-59
         X[1][k] = (double)(Cr - 128);
         X[2][k] = (double)(Cb - 128);
     }
 
     const size_t plane = (size_t)g.H * g.W;
-    typename CoeffT<CM>::type *__restrict__ out = planes + (size_t)f * planes_stride;
+    using OutT = typename CoeffT<CM>::type;
+    OutT *__restrict__ out = planes + (size_t)f * planes_stride;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         // stage 1: T = D * X (DCTcompressor.py:113), lane holds column j
@@ -119,17 +139,34 @@ __global__ __launch_bounds__(64) void k_fdct(
         double T[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) T[k] = s_t[t * kTilePad + j * 8 + k];
-        __syncthreads();
-        if (live) {
-            const int xo = gx * 64 + t * 8;
-            typename CoeffT<CM>::type *o = out + ch * plane + (size_t)(ty * 8 + j) * g.W + xo;
+        {
             const double *q = Q + ch * 64 + j * 8;
+            const double *rq = q + 192;  // correctly rounded 1 / Q
 #pragma unroll
             for (int jj = 0; jj < 8; jj++) {
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < 8; k++) acc = __builtin_fma(T[k], D[jj * 8 + k], acc);
-                o[jj] = coeff_pack<CM>(acc / q[jj]);  // :71 np.true_divide
+                // :71 np.true_divide; parked for the row-contiguous store below
+                s_o[(t * 8 + j) * kOutPad + jj] = coeff_pack<CM>(
+                    FASTDIV ? div_markstein(acc, q[jj], rq[jj]) : acc / q[jj]);
+            }
+        }
+        __syncthreads();
+        // row-contiguous store: one wave instruction covers two whole 64-column rows
+        // of the strip (lane l -> columns 2*(l%32), +1 of row 2*s + l/32) instead of
+        // 64 scattered 16-byte pieces -- the planes are 80 % of the kernel's HBM bytes
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            const int e = s4 * 64 + lane, row = e >> 5, c2 = e & 31;
+            const int tt = c2 >> 2, jj = (c2 & 3) * 2;
+            const int xc = gx * 64 + 2 * c2;
+            if (xc < g.W) {
+                const OutT v0 = s_o[(tt * 8 + row) * kOutPad + jj];
+                const OutT v1 = s_o[(tt * 8 + row) * kOutPad + jj + 1];
+                OutT *o = out + ch * plane + (size_t)(ty * 8 + row) * g.W + xc;
+                struct alignas(2 * sizeof(OutT)) Pair { OutT a, b; };
+                *(Pair *)o = Pair{v0, v1};
             }
         }
     }
@@ -198,11 +235,10 @@ __global__ __launch_bounds__(64) void k_idct(
         int B, G, R;
         ycc2bgr(ycc[0][jj], ycc[1][jj], ycc[2][jj], B, G, R);  // :92
         if (MODE == 1) {  // decoder.py:57 img + decompressed, uint8 wrap
-            int p0, p1, p2;
-            pred_px(ref, mv, g, y, xo + jj, p0, p1, p2);
-            B = (B + p0) & 255;
-            G = (G + p1) & 255;
-            R = (R + p2) & 255;
+            const uint32_t p = pred_px(ref, mv, g, y, xo + jj);
+            B = (B + (int)(p & 255)) & 255;
+            G = (G + (int)((p >> 8) & 255)) & 255;
+            R = (R + (int)((p >> 16) & 255)) & 255;
         }
         o[3 * jj + 0] = (uint8_t)B;
         o[3 * jj + 1] = (uint8_t)G;

@@ -48,8 +48,9 @@ struct vcs_ctx {
     unsigned long long *d_cost = nullptr;
     uint32_t *d_ns = nullptr;
     void *d_planes = nullptr;
-    double *d_DQ = nullptr;  // D[64] + Q[192]
-    double hDQ[256];
+    double *d_DQ = nullptr;  // D[64] + Q[192] + 1/Q[192]
+    double hDQ[448];
+    bool fastdiv = false;    // Q table admits the 3-FMA exact division
     // GOP buffers
     int slots = 0;
     bool gop_dec = false;
@@ -130,6 +131,26 @@ int refresh_me_geometry(vcs_ctx *c) {
     return VCS_OK;
 }
 
+// Fills 1/Q behind Q and decides whether the 3-FMA division is exact for it:
+// every |Q| within [2^-60, 2^60] and no all-ones significand (Markstein).
+void refresh_q(vcs_ctx *c) {
+    bool ok = true;
+    for (int i = 0; i < 192; i++) {
+        const double q = c->hDQ[64 + i];
+        c->hDQ[256 + i] = 1.0 / q;
+        uint64_t bits;
+        memcpy(&bits, &q, 8);
+        const double aq = fabs(q);
+        if (!(aq >= 0x1p-60 && aq <= 0x1p60) || (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull)
+            ok = false;
+    }
+    // Opt-in (VCS_FAST_DIV=1): measured on MI355X the fused tail kernel is bound by
+    // its float64 stores, and the extra 1/Q loads cost more than the IEEE division
+    // sequence saves (0.64 vs 0.60 ms per 29-frame GOP), so the default stays IEEE.
+    const char *e = getenv("VCS_FAST_DIV");
+    c->fastdiv = ok && e && e[0] == '1';
+}
+
 // ---- timing brackets -----------------------------------------------------
 int t_begin(vcs_ctx *c, int slot, EvPair *ev) {
     c->launches[slot]++;
@@ -203,20 +224,21 @@ int launch_fdct(vcs_ctx *c, int tslot, const uint8_t *imgs, size_t stride, const
     EvPair ev;
     int rc = t_begin(c, tslot, &ev);
     if (rc) return rc;
+#define VCS_FDCT(CM, FD, T)                                                                  \
+    hipLaunchKernelGGL((k_fdct<MODE, CM, FD>), grid, block, 0, c->stream, imgs, stride, ref, mv, \
+                       g, c->d_DQ, (T *)planes, pstride_elems)
     switch (c->coeff_mode) {
         case VCS_COEFF_F64:
-            hipLaunchKernelGGL((k_fdct<MODE, 0>), grid, block, 0, c->stream, imgs, stride, ref, mv,
-                               g, c->d_DQ, (double *)planes, pstride_elems);
+            if (c->fastdiv) VCS_FDCT(0, true, double); else VCS_FDCT(0, false, double);
             break;
         case VCS_COEFF_F32:
-            hipLaunchKernelGGL((k_fdct<MODE, 1>), grid, block, 0, c->stream, imgs, stride, ref, mv,
-                               g, c->d_DQ, (float *)planes, pstride_elems);
+            if (c->fastdiv) VCS_FDCT(1, true, float); else VCS_FDCT(1, false, float);
             break;
         default:
-            hipLaunchKernelGGL((k_fdct<MODE, 2>), grid, block, 0, c->stream, imgs, stride, ref, mv,
-                               g, c->d_DQ, (int16_t *)planes, pstride_elems);
+            if (c->fastdiv) VCS_FDCT(2, true, int16_t); else VCS_FDCT(2, false, int16_t);
             break;
     }
+#undef VCS_FDCT
     return t_end(c, &ev);
 }
 
@@ -426,11 +448,12 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     CREATE_TRY(hipMalloc(&c->d_coords, nmv * 2 * sizeof(int32_t)));
     CREATE_TRY(hipMalloc(&c->d_cost, nmv * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(&c->d_ns, sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc(&c->d_DQ, sizeof(double) * 256));
+    CREATE_TRY(hipMalloc(&c->d_DQ, sizeof(double) * 448));
 #undef CREATE_TRY
     vcs_dct_matrix(c->hDQ);
     vcs_make_q(50.0, c->hDQ + 64);  // DCTcompressor.py:29
-    hipError_t e3 = hipMemcpy(c->d_DQ, c->hDQ, sizeof(double) * 256, hipMemcpyHostToDevice);
+    refresh_q(c);
+    hipError_t e3 = hipMemcpy(c->d_DQ, c->hDQ, sizeof(double) * 448, hipMemcpyHostToDevice);
     if (e3 != hipSuccess) {
         fail(nullptr, VCS_E_HIP, "hipMemcpy(DQ): %s", hipGetErrorString(e3));
         vcs_ctx_destroy(c);
@@ -483,8 +506,9 @@ int vcs_set_params(vcs_ctx *c, int win, int step, int64_t sim_thresh, const doub
     c->coeff_mode = coeff_mode;
     if (Q) {
         memcpy(c->hDQ + 64, Q, sizeof(double) * 192);
+        refresh_q(c);
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipMemcpy(c->d_DQ, c->hDQ, sizeof(double) * 256, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_DQ, c->hDQ, sizeof(double) * 448, hipMemcpyHostToDevice));
     }
     return VCS_OK;
 }
@@ -830,6 +854,29 @@ int vcs_measure_copy_bw(vcs_ctx *c, size_t bytes, int iters, double *gbps_out) {
     hipFree(a); hipFree(b);
     if (e != hipSuccess) return fail(c, VCS_E_HIP, "copy benchmark: %s", hipGetErrorString(e));
     *gbps_out = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;  // read + write
+    return VCS_OK;
+}
+
+int vcs_measure_fill_bw(vcs_ctx *c, size_t bytes, int iters, double *gbps_out) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!gbps_out || bytes < 1024 || iters < 1) return fail(c, VCS_E_ARG, "bad arguments");
+    void *a = nullptr;
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipMalloc(&a, bytes));
+    hipMemsetAsync(a, 1, bytes, c->stream);  // warm
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, c->stream);
+    for (int i = 0; i < iters; i++) hipMemsetAsync(a, i, bytes, c->stream);
+    hipEventRecord(e1, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a);
+    if (e != hipSuccess) return fail(c, VCS_E_HIP, "fill benchmark: %s", hipGetErrorString(e));
+    *gbps_out = (double)bytes * iters / (ms * 1e-3) / 1e9;  // write only
     return VCS_OK;
 }
 

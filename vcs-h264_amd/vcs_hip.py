@@ -60,6 +60,7 @@ SIGNATURES = {
     "vcs_timing_reset": (ctypes.c_int, [_c_ctx]),
     "vcs_timing": (ctypes.c_int, [_c_ctx, _f64p, _u64p, ctypes.c_int]),
     "vcs_measure_copy_bw": (ctypes.c_int, [_c_ctx, ctypes.c_size_t, ctypes.c_int, _f64p]),
+    "vcs_measure_fill_bw": (ctypes.c_int, [_c_ctx, ctypes.c_size_t, ctypes.c_int, _f64p]),
 }
 
 _LIB = None
@@ -323,4 +324,9 @@ class Context:
     def measure_copy_bw(self, nbytes=1 << 30, iters=10):
         g = ctypes.c_double(0)
         self._ck(self._lib.vcs_measure_copy_bw(self._h, int(nbytes), int(iters), ctypes.byref(g)))
+        return g.value
+
+    def measure_fill_bw(self, nbytes=1 << 30, iters=10):
+        g = ctypes.c_double(0)
+        self._ck(self._lib.vcs_measure_fill_bw(self._h, int(nbytes), int(iters), ctypes.byref(g)))
         return g.value
