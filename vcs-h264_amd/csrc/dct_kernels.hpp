@@ -59,17 +59,19 @@ __device__ __forceinline__ double div_markstein(double a, double b, double y) {
 
 // Predicted (motion-compensated) pixel for frame position (y, x), or 0 where
 // no full motion block covers it (motion.py:45-46, :83-87).  Low 3 bytes: B G R.
+// Branch-free: the coordinates are clamped into the covered area so that both
+// loads are unconditional (a conditional load makes hipcc wait for it on the
+// spot, which serialises the eight rows of a strip), and the result is
+// selected afterwards.  Needs g.N > 0.
 __device__ __forceinline__ uint32_t pred_px(const uint8_t *__restrict__ ref,
                                             const int16_t *__restrict__ mv, const Geom &g,
                                             int y, int x) {
-    uint32_t v = 0;
-    if (y < g.nby * g.bs && x < g.nbx * g.bs) {
-        const int blk = (y / g.bs) * g.nbx + (x / g.bs);
-        const uint32_t m = load_px((const uint8_t *)(mv + 2 * blk));  // dx | dy << 16
-        const int dx = (int16_t)(m & 0xFFFFu), dy = (int16_t)(m >> 16);
-        v = load_px(ref + (size_t)(y + dy) * g.pitch + (size_t)(3 * (x + dx)));
-    }
-    return v;
+    const int yc = min(y, g.nby * g.bs - 1), xc = min(x, g.nbx * g.bs - 1);
+    const int blk = (yc / g.bs) * g.nbx + (xc / g.bs);
+    const uint32_t m = load_px((const uint8_t *)(mv + 2 * blk));  // dx | dy << 16
+    const int dx = (int16_t)(m & 0xFFFFu), dy = (int16_t)(m >> 16);
+    const uint32_t v = load_px(ref + (size_t)(yc + dy) * g.pitch + (size_t)(3 * (xc + dx)));
+    return (yc == y && xc == x) ? v : 0u;
 }
 
 // --------------------------------------------------------------------------
@@ -86,29 +88,33 @@ __global__ __launch_bounds__(64) void k_fdct(
     typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride) {
     __shared__ double s_t[8 * kTilePad];
     __shared__ typename CoeffT<CM>::type s_o[64 * kOutPad];  // [tile][row][col], padded rows
+    __shared__ double s_q[48 * kOutPad];  // Q[3][8][8] then 1/Q, rows padded to 9
     const int lane = threadIdx.x;
     const int t = lane >> 3, j = lane & 7;
     const int groups_x = (g.W + 63) >> 6;
     const int ty = blockIdx.x / groups_x, gx = blockIdx.x - ty * groups_x;
     const int f = blockIdx.y;
     const int x = gx * 64 + lane;  // stage-1 pixel column of this lane
-    const bool live = x < g.W;     // W is a multiple of 8: tiles are whole
     const uint8_t *__restrict__ img = imgs + (size_t)f * img_stride;
     const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
     const double *__restrict__ D = DQ;
     const double *__restrict__ Q = DQ + 64;
 
-    // ---- fetch column x of the 8-row strip, form the residual, convert -----
+    // ---- Q (and 1/Q) into LDS: later reads must not share vmcnt with the stores --
+    for (int e = lane; e < (FASTDIV ? 384 : 192); e += 64) {
+        const int row = e >> 3;
+        s_q[row * kOutPad + (e & 7)] = Q[e];
+    }
+    // ---- fetch column x of the 8-row strip (all loads unconditional) ---------
+    const int xl = min(x, g.W - 1);
     uint32_t px[8], pp[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        px[k] = pp[k] = 0;
-        if (live) {
-            const int y = ty * 8 + k;
-            px[k] = load_px(img + (size_t)y * g.pitch + (size_t)(3 * x));
-            if (MODE == 1) pp[k] = pred_px(ref, mv, g, y, x);
-        }
+        const int y = ty * 8 + k;
+        px[k] = load_px(img + (size_t)y * g.pitch + (size_t)(3 * xl));
+        pp[k] = MODE == 1 ? pred_px(ref, mv, g, y, xl) : 0u;
     }
+    wave_lds_fence();
     double X[3][8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -134,14 +140,14 @@ __global__ __launch_bounds__(64) void k_fdct(
             for (int k = 0; k < 8; k++) acc = __builtin_fma(D[i * 8 + k], X[ch][k], acc);
             s_t[t * kTilePad + i * 8 + j] = acc;
         }
-        __syncthreads();
+        wave_lds_fence();
         // stage 2: R = T * D^T (:114), lane (t, i = j) holds row i of T
         double T[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) T[k] = s_t[t * kTilePad + j * 8 + k];
         {
-            const double *q = Q + ch * 64 + j * 8;
-            const double *rq = q + 192;  // correctly rounded 1 / Q
+            const double *q = s_q + (ch * 8 + j) * kOutPad;
+            const double *rq = q + 24 * kOutPad;  // correctly rounded 1 / Q
 #pragma unroll
             for (int jj = 0; jj < 8; jj++) {
                 double acc = 0.0;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(64) void k_fdct(
                     FASTDIV ? div_markstein(acc, q[jj], rq[jj]) : acc / q[jj]);
             }
         }
-        __syncthreads();
+        wave_lds_fence();
         // row-contiguous store: one wave instruction covers two whole 64-column rows
         // of the strip (lane l -> columns 2*(l%32), +1 of row 2*s + l/32) instead of
         // 64 scattered 16-byte pieces -- the planes are 80 % of the kernel's HBM bytes
@@ -213,11 +219,11 @@ __global__ __launch_bounds__(64) void k_idct(
             for (int k = 0; k < 8; k++) acc = __builtin_fma(D[k * 8 + i], X[k], acc);
             s_t[t * kTilePad + i * 8 + j] = acc;
         }
-        __syncthreads();
+        wave_lds_fence();
         double T[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) T[k] = s_t[t * kTilePad + j * 8 + k];
-        __syncthreads();
+        wave_lds_fence();
         // stage 2: R = T * D (:120); truncating uint8 store (:88), + 128 (:89)
 #pragma unroll
         for (int jj = 0; jj < 8; jj++) {

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64, 2) void k_me16(
                     if (e < 16 * 13) s_cur[row * 16 + j] = ~A.cq[t] | padm;
                 }
             }
-            __syncthreads();
+            wave_lds_fence();
 
             // ---- candidate grid (motion.py:132-140) ---------------------------------
             const int i_min = max(y - WIN, 0), j_min = max(x - WIN, 0);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64, 2) void k_me16(
                     if (cost_out) cost_out[oidx] = c;
                 }
             }
-            __syncthreads();  // the window is rewritten by the next block
+            wave_lds_fence();  // the window is rewritten by the next block
         }
         if (wn >= w_end) break;  // wave-uniform; every wave leaves after its share
         w = wn;

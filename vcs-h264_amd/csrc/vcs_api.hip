@@ -616,7 +616,8 @@ int vcs_encode_p(vcs_ctx *c, const uint8_t *cur, int16_t *mv_out, void *planes_o
     rc = launch_me(c, c->d_ref, c->d_cur, c->Fs, 1, c->d_mv, c->d_ns, nullptr);
     if (rc) return rc;
     if (planes_out) {
-        rc = launch_fdct<1>(c, VCS_T_ENC_TAIL, c->d_cur, c->Fs, c->d_ref, c->d_mv, 1, c->d_planes, 0);
+        rc = N ? launch_fdct<1>(c, VCS_T_ENC_TAIL, c->d_cur, c->Fs, c->d_ref, c->d_mv, 1, c->d_planes, 0)
+               : launch_fdct<0>(c, VCS_T_ENC_TAIL, c->d_cur, c->Fs, nullptr, nullptr, 1, c->d_planes, 0);
         if (rc) return rc;
         HIP_TRY(c, hipMemcpyAsync(planes_out, c->d_planes, planes_bytes(c), hipMemcpyDeviceToHost, c->stream));
     }
@@ -648,7 +649,8 @@ int vcs_decode_p(vcs_ctx *c, const int16_t *mv, const void *planes, uint8_t *bgr
     if (planes) {
         if ((rc = need_dct_geometry(c)) || (rc = ensure_planes(c))) return rc;
         HIP_TRY(c, hipMemcpyAsync(c->d_planes, planes, planes_bytes(c), hipMemcpyHostToDevice, c->stream));
-        rc = launch_idct<1>(c, VCS_T_DEC, c->d_planes, 0, c->d_ref, c->d_mv, 1, c->d_a, c->Fs);
+        rc = N ? launch_idct<1>(c, VCS_T_DEC, c->d_planes, 0, c->d_ref, c->d_mv, 1, c->d_a, c->Fs)
+               : launch_idct<0>(c, VCS_T_DEC, c->d_planes, 0, nullptr, nullptr, 1, c->d_a, c->Fs);
     } else {
         rc = launch_mc(c, c->d_mv, nullptr, (int)N, c->d_a);
     }
@@ -713,6 +715,8 @@ int vcs_gop_encode(vcs_ctx *c, int first, int n) {
     if (rc) return rc;
     size_t pe = (size_t)3 * c->g.H * c->g.W;
     void *planes = (char *)c->g_planes + (size_t)first * planes_bytes(c);
+    if (N == 0)  // no full motion block: the prediction is all zero (motion.py:45-46)
+        return launch_fdct<0>(c, VCS_T_ENC_TAIL, curs, c->Fs, nullptr, nullptr, n, planes, pe);
     return launch_fdct<1>(c, VCS_T_ENC_TAIL, curs, c->Fs, c->d_ref, mv, n, planes, pe);
 }
 
@@ -723,6 +727,9 @@ int vcs_gop_decode(vcs_ctx *c, int first, int n) {
     if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
     size_t N = c->g.N, pe = (size_t)3 * c->g.H * c->g.W;
     const void *planes = (const char *)c->g_planes + (size_t)first * planes_bytes(c);
+    if (N == 0)
+        return launch_idct<0>(c, VCS_T_DEC, planes, pe, nullptr, nullptr, n,
+                              c->g_dec + (size_t)first * c->Fs, c->Fs);
     return launch_idct<1>(c, VCS_T_DEC, planes, pe, c->d_ref, c->g_mv + (size_t)first * N * 2, n,
                           c->g_dec + (size_t)first * c->Fs, c->Fs);
 }

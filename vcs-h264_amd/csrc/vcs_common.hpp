@@ -32,6 +32,19 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
+// ---- LDS hand-off between the lanes of ONE wave ---------------------------
+// Every kernel here runs single-wave workgroups.  The DS operations of a wave
+// execute in order, so lanes can exchange data through LDS without s_barrier;
+// what is needed is only that the compiler keeps the write -> read order.
+// __syncthreads() must NOT be used for this: its fence also drains vmcnt, i.e.
+// it waits for every outstanding global load (the register prefetch of the next
+// block in k_me16) and global store (the coefficient planes in k_fdct).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- packed-byte arithmetic ---------------------------------------------
 // Per-byte (a - b) mod 256 on four packed bytes, no borrow across bytes.
 __device__ __forceinline__ uint32_t sub_u8x4(uint32_t a, uint32_t b) {
