@@ -52,17 +52,15 @@ def cpu_baseline(H, W, bs, ref, frames, budget_s=12.0):
     oracle.encode_p(frames[0][:64, :64].copy(), ref[:64, :64].copy(), bs)  # warm (build/load)
     t0 = time.perf_counter()
     done = 0
-    for k in range(len(frames)):
-        oracle.encode_p(frames[k], ref, bs)
+    while time.perf_counter() - t0 < budget_s:   # cycle through the GOP until the budget is used
+        oracle.encode_p(frames[done % len(frames)], ref, bs)
         done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
     dt = time.perf_counter() - t0
     N = (H // bs) * (W // bs)
     return {"value": round(done * N / dt / 1e3, 3), "unit": "macroblocks/ms", "cores": cores,
             "kind": "port",
-            "sample": "%d of the GOP's P frames (%dx%d, ME %dx%d + 8x8 DCT), oracle/vcs_oracle.c "
-                      "with OpenMP, %.1f s" % (done, W, H, bs, bs, dt)}
+            "sample": "%d P-frame encodes cycling through the GOP (%dx%d, ME %dx%d + 8x8 DCT), "
+                      "oracle/vcs_oracle.c with OpenMP, %.1f s" % (done, W, H, bs, bs, dt)}
 
 
 def main():
@@ -161,10 +159,30 @@ def main():
         # algorithmic HBM bytes per macroblock: ME reads cur + ref and
         # writes the vectors; the tail reads cur + ref + vectors, writes 3 f64 planes
         per_mb = {vcs_hip.T_ME: (2 * F + 4 * N) / N, vcs_hip.T_ENC_TAIL: (10 * F + 4 * N) / N}
-        names = {vcs_hip.T_ME: "k_me", vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
+        names = {vcs_hip.T_ME: "k_me16" if bs == 16 else "k_me_generic",
+                 vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
+        # PMC-measured HBM bytes per launch of the same workload (profiles/hbm_traffic.json,
+        # produced by profiles/collect.sh; FETCH_SIZE doubled per the gfx950 correction)
+        traffic = {}
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "hbm_traffic.json")))
+            wl = tj["workload"]
+            if (wl["H"], wl["W"], wl["frames_per_launch"], wl["me_bs"]) == (H, W, n, bs):
+                traffic = {k: v["hbm_bytes_corrected"] for k, v in tj["kernels"].items()}
+        except (OSError, KeyError, ValueError):
+            pass
+
+        def roof(slot):
+            avg_ms = ms[slot] / max(1, int(launches[slot]))
+            alg = per_mb[slot] * n * N
+            ach = alg / (avg_ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": names[slot], "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic.get(names[slot]),
+                    "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_ms, 4)}
+
         dom = max(per_mb, key=lambda k: ms[k])
-        avg_ms = ms[dom] / max(1, int(launches[dom]))
-        achieved = per_mb[dom] * n * N / (avg_ms * 1e-3) / 1e9
+        other = vcs_hip.T_ENC_TAIL if dom == vcs_hip.T_ME else vcs_hip.T_ME
         out = {
             "metric": "macroblocks/ms (16x16, ME+DCT encode) at 1080p +-32px search",
             "value": round(value, 2), "unit": "macroblocks/ms",
@@ -181,12 +199,26 @@ def main():
                        "parallelism": "P frames sharded over %d GPU(s)" % world},
             "kernel_ms_per_step": {"me": round(ms[vcs_hip.T_ME] / args.steps, 4),
                                    "enc_tail": round(ms[vcs_hip.T_ENC_TAIL] / args.steps, 4)},
-            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(per_mb[dom] * n * N),
-                         "avg_launch_ms": round(avg_ms, 4)},
+            "roofline": roof(dom),
+            "roofline_second_kernel": roof(other),
         }
+        if names[vcs_hip.T_ME] == "k_me16":
+            # the motion search is bound by vector-ALU issue, not by HBM: say how close it
+            # is to THAT roof (wave-instructions per launch from profiles/r01 PMC, 16-lane
+            # SIMDs issue one wave64 instruction per 4 cycles)
+            valu_per_mb = 1470.0
+            peak = 256 * 4 * 2.4e9 / 4
+            me_ms = ms[vcs_hip.T_ME] / max(1, int(launches[vcs_hip.T_ME]))
+            ach = valu_per_mb * n * N / (me_ms * 1e-3)
+            out["k_me16_valu_issue"] = {"achieved_ginst_s": round(ach / 1e9, 1),
+                                        "peak_ginst_s": round(peak / 1e9, 1),
+                                        "frac": round(ach / peak, 3),
+                                        "valu_wave_insts_per_macroblock": valu_per_mb}
+        try:
+            out["hbm_measured_gbs"] = {"copy_read_plus_write": round(ctx.measure_copy_bw(1 << 28, 5), 0),
+                                       "fill_write_only": round(ctx.measure_fill_bw(1 << 28, 5), 0)}
+        except vcs_hip.VcsError:
+            pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W, bs, ref, frames)
         else:

@@ -366,3 +366,18 @@ def test_error_paths(vh):
     with vh.Context(50, 70, 8) as c:  # DCT path refuses non-multiples of 8
         with pytest.raises(vh.VcsError):
             c.compress(np.zeros((50, 70, 3), np.uint8))
+
+
+def test_gop_encoder_single_rank(vh, oracle):
+    """gop.DistGopEncoder with the product (HIP) backend, world size 1."""
+    from gop import DistGopEncoder
+    from synth import synth_gop
+    H, W, n = 144, 176, 5
+    ref, frames = synth_gop(H, W, n, seed=8)
+    enc = DistGopEncoder(H, W, 16, n_frames=n)
+    mv, ns = enc.encode_gop(ref, frames)
+    for k in range(n):
+        omv, oplanes, ons = oracle.encode_p(frames[k], ref, 16)
+        assert np.array_equal(mv[k], omv) and ns[k] == ons
+        assert np.array_equal(enc.backend.planes(k), oplanes)
+    enc.backend.close()
