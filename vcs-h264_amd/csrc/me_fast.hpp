@@ -37,7 +37,10 @@
 //     one XCD are contiguous in the frame (reference-window reuse in that
 //     XCD's L2); the result never depends on the mapping.
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #include "vcs_common.hpp"
 
@@ -54,25 +57,20 @@ __device__ __forceinline__ uint4 load16_any_align(const uint8_t *p) {
     return v;
 }
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t t = __shfl_xor(v, o, 64);
-        v = t < v ? t : v;
-    }
-    return v;
-}
-
-// 16 dwords of LDS (four ds_read_b128) starting at p.  keep4: force the 4th
-// read to stay a conflict-free ds_read_b128 -- only its first dword is used,
-// but as a ds_read_b32 the 16-byte lane stride would land 32 lanes on 8 banks.
+// 16 dwords of LDS (four ds_read_b128) starting at p.
 struct Me16Q {
     uint4 q0, q1, q2, q3;
 };
-__device__ __forceinline__ void me16_ld(Me16Q &Q, const void *p, bool keep4) {
+__device__ __forceinline__ void me16_ld(Me16Q &Q, const void *p) {
     const uint4 *a = (const uint4 *)p;
     Q.q0 = a[0]; Q.q1 = a[1]; Q.q2 = a[2]; Q.q3 = a[3];
-    if (keep4) asm volatile("" ::"v"(Q.q3.y), "v"(Q.q3.z), "v"(Q.q3.w));
+}
+// Only the first dword of the 4th read is used.  Pretending to use the rest AT
+// THE POINT OF CONSUMPTION keeps it a conflict-free ds_read_b128 (as a
+// ds_read_b32 the 16-byte lane stride would land 32 lanes on 8 banks) without
+// forcing a wait right behind the load.
+__device__ __forceinline__ void me16_keep4(const Me16Q &Q) {
+    asm volatile("" ::"v"(Q.q3.y), "v"(Q.q3.z), "v"(Q.q3.w));
 }
 
 // #{r >= c} over the 13 dwords of one candidate row.  A dependent VALU
@@ -87,6 +85,7 @@ __device__ __forceinline__ void me16_count13(const Me16Q &a, const Me16Q &c, uin
                             a.q1.w, a.q2.x, a.q2.y, a.q2.z, a.q2.w, a.q3.x};
     const uint32_t nc[13] = {c.q0.x, c.q0.y, c.q0.z, c.q0.w, c.q1.x, c.q1.y, c.q1.z,
                              c.q1.w, c.q2.x, c.q2.y, c.q2.z, c.q2.w, c.q3.x};
+    me16_keep4(a);
     uint32_t t[13];
 #pragma unroll
     for (int d = 0; d < 13; d++) t[d] = __builtin_amdgcn_lerp(r[d], nc[d], 0x01010101u);
@@ -101,6 +100,7 @@ __device__ __forceinline__ void me16_count13(const Me16Q &a, const Me16Q &c, uin
 }
 // Byte sum of the 13 dwords (the 13th holds 3 data bytes + one foreign byte).
 __device__ __forceinline__ void me16_sum13(const Me16Q &a, uint32_t (&sum)[4]) {
+    me16_keep4(a);
     const uint32_t r[13] = {a.q0.x, a.q0.y, a.q0.z, a.q0.w, a.q1.x, a.q1.y, a.q1.z,
                             a.q1.w, a.q2.x, a.q2.y, a.q2.z, a.q2.w, a.q3.x & 0x00FFFFFFu};
 #pragma unroll
@@ -108,27 +108,55 @@ __device__ __forceinline__ void me16_sum13(const Me16Q &a, uint32_t (&sum)[4]) {
 }
 
 // All 16 rows of two candidates per lane (p0: candidate `lane`, p1: candidate
-// `lane + 64`) against the same re-packed current rows.  MODE kSums: byte sums
-// instead of counts.
+// `lane + 64`) against the same re-packed current rows, fully unrolled and
+// software-pipelined one row ahead: the LDS reads of row k+1 are issued before
+// row k is evaluated (two waves per SIMD do not cover the LDS latency on their
+// own).  Scheduling fences keep hipcc from hoisting more than that one row
+// (which spills).  MODE kSums: byte sums instead of counts.
 template <int MODE, bool TWO, int ROWB>
 __device__ __forceinline__ void me16_rows(const uint32_t *s_cur, const uint8_t *p0,
                                           const uint8_t *p1, uint32_t (&acc0)[4],
                                           uint32_t (&acc1)[4]) {
-#pragma unroll 4
+    Me16Q c[2], a[2], b[2];
+    if (MODE == kMe16Search) me16_ld(c[0], s_cur);
+    me16_ld(a[0], p0);
+    if (TWO) me16_ld(b[0], p1);
+#pragma unroll
     for (int k = 0; k < 16; k++) {
-        Me16Q c, a, b;
-        if (MODE == kMe16Search) me16_ld(c, s_cur + k * 16, false);
-        me16_ld(a, p0 + k * ROWB, true);
-        if (TWO) me16_ld(b, p1 + k * ROWB, true);
+        const int cur = k & 1, nxt = cur ^ 1;
+        if (k + 1 < 16) {
+            if (MODE == kMe16Search) me16_ld(c[nxt], s_cur + (k + 1) * 16);
+            me16_ld(a[nxt], p0 + (k + 1) * ROWB);
+            if (TWO) me16_ld(b[nxt], p1 + (k + 1) * ROWB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (MODE == kMe16Search) {
-            me16_count13(a, c, acc0);
-            if (TWO) me16_count13(b, c, acc1);
+            me16_count13(a[cur], c[cur], acc0);
+            if (TWO) me16_count13(b[cur], c[cur], acc1);
         } else {
-            me16_sum13(a, acc0);
-            if (TWO) me16_sum13(b, acc1);
+            me16_sum13(a[cur], acc0);
+            if (TWO) me16_sum13(b[cur], acc1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
+
+// Diagnostic build only (-DVCS_ME16_STAMPS): s_memtime at phase boundaries,
+// summed per wave into cost_out[wave * 8 + phase] (shares, never quote its run
+// time).  No stamp executes in the product build.
+#ifdef VCS_ME16_STAMPS
+#define ME16_STAMP(i)                                                                        \
+    do {                                                                                     \
+        unsigned long long t_;                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        st_acc[i] += t_ - st_prev;                                                           \
+        st_prev = t_;                                                                        \
+    } while (0)
+#else
+#define ME16_STAMP(i) do { } while (0)
+#endif
 
 // Everything one block needs from HBM, held in registers until it is used.
 struct Me16Regs {
@@ -208,8 +236,8 @@ __device__ __forceinline__ void me16_issue(const uint8_t *__restrict__ ref,
 // MODE kMe16Search: motion search of `total` work items (frame-major blocks).
 // MODE kMe16Sums:   fills sums[blk * 128 + cand] for the N blocks of `ref`.
 // SLOTS: 16-byte slots per LDS window row (18 = conflict-free, 14 = denser).
-template <int SLOTS, int MODE>
-__global__ __launch_bounds__(64, 2) void k_me16(
+template <int SLOTS, int MODE, bool PREFETCH = true>
+__global__ __launch_bounds__(64, PREFETCH ? 2 : 3) void k_me16(
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
     Geom g, int total, uint32_t *__restrict__ sums, int16_t *__restrict__ mv,
     uint32_t *__restrict__ n_static, unsigned long long *__restrict__ cost_out) {
@@ -232,13 +260,21 @@ __global__ __launch_bounds__(64, 2) void k_me16(
     Me16Offs O;
     me16_offsets(g, lane, O);
     Me16Regs A;
-    me16_issue<MODE>(ref, curs, cur_stride, sums, g, w, lane, O, A);
+    if (PREFETCH) me16_issue<MODE>(ref, curs, cur_stride, sums, g, w, lane, O, A);
+#ifdef VCS_ME16_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
 
     for (;;) {
         // ---- prefetch the next block of this wave while this one is searched ------
         const int wn = w + nw;
         Me16Regs B;
-        me16_issue<MODE>(ref, curs, cur_stride, sums, g, min(wn, w_end - 1), lane, O, B);
+        if (PREFETCH)
+            me16_issue<MODE>(ref, curs, cur_stride, sums, g, min(wn, w_end - 1), lane, O, B);
+        else  // no register double-buffering: fewer VGPRs, a third wave per SIMD covers the latency
+            me16_issue<MODE>(ref, curs, cur_stride, sums, g, w, lane, O, A);
+        ME16_STAMP(0);  // issue of the next block's loads
 
         const int f = w / g.N, blk = w - f * g.N;
         const int byi = blk / g.nbx, bxi = blk - byi * g.nbx;
@@ -250,25 +286,29 @@ __global__ __launch_bounds__(64, 2) void k_me16(
         bool is_static = false;
         uint32_t s_c = 0;
         if (MODE == kMe16Search) {
-            uint32_t s_abs = 0, s_r = 0;
+            uint32_t s_d = 0;  // |r - c| + r - c = 2 * max(r - c, 0) per byte: never negative
 #pragma unroll
             for (int t = 0; t < 3; t++) {
-                s_abs = __builtin_amdgcn_sad_u8(A.rv[t], A.cv[t], s_abs);
-                s_r = __builtin_amdgcn_sad_u8(A.rv[t], 0u, s_r);
+                s_d = __builtin_amdgcn_sad_u8(A.rv[t], A.cv[t], s_d);
+                s_d = __builtin_amdgcn_sad_u8(A.rv[t], 0u, s_d);
                 s_c = __builtin_amdgcn_sad_u8(A.cv[t], 0u, s_c);
             }
-            s_abs = wave_sum_u32(s_abs);
-            s_r = wave_sum_u32(s_r);
+            // per lane: s_d holds sad(r,c) + sum(r); subtracting this lane's sum(c) keeps
+            // it >= 0, so one reduction gives 2 * sum(max(r - c, 0)) and one gives sum(c)
+            s_d = wave_sum_u32(s_d - s_c);
             s_c = wave_sum_u32(s_c);  // sum of the current block's bytes
-            const uint32_t sdiff = (s_abs + s_r - s_c) >> 1;
+            const uint32_t sdiff = s_d >> 1;
             is_static = !g.never_static && sdiff <= g.thresh;
             if (is_static && lane == 0) {
                 mv[2 * oidx + 0] = 0;
                 mv[2 * oidx + 1] = 0;
                 atomicAdd(&n_static[f], 1u);
+#ifndef VCS_ME16_STAMPS
                 if (cost_out) cost_out[oidx] = sdiff;
+#endif
             }
         }
+        ME16_STAMP(1);  // static test (waits for this block's co-located loads)
         if (!is_static) {
             // ---- park the window in 5-pixel groups (motion.py:125-129) -------------
 #pragma unroll
@@ -288,6 +328,7 @@ __global__ __launch_bounds__(64, 2) void k_me16(
                 }
             }
             wave_lds_fence();
+            ME16_STAMP(2);  // window + current block parked (waits for this block's window loads)
 
             // ---- candidate grid (motion.py:132-140) ---------------------------------
             const int i_min = max(y - WIN, 0), j_min = max(x - WIN, 0);
@@ -310,6 +351,7 @@ __global__ __launch_bounds__(64, 2) void k_me16(
             else
                 me16_rows<MODE, false, kRowB>(s_cur, p0, p1, acc0, acc1);
 
+            ME16_STAMP(3);  // the row loop
             if (MODE == kMe16Sums) {
                 uint32_t *__restrict__ sb = sums + (size_t)blk * kMe16SumStride;
                 sb[cand0] = act0 ? acc0[0] + acc0[1] + acc0[2] + acc0[3] : 0u;
@@ -335,15 +377,23 @@ __global__ __launch_bounds__(64, 2) void k_me16(
                     }
                     mv[2 * oidx + 0] = (int16_t)(bx - x);
                     mv[2 * oidx + 1] = (int16_t)(by - y);
+#ifndef VCS_ME16_STAMPS
                     if (cost_out) cost_out[oidx] = c;
+#endif
                 }
             }
             wave_lds_fence();  // the window is rewritten by the next block
+            ME16_STAMP(4);  // reduction + result store
         }
         if (wn >= w_end) break;  // wave-uniform; every wave leaves after its share
         w = wn;
-        A = B;
+        if (PREFETCH) A = B;
+        ME16_STAMP(5);  // register hand-over
     }
+#ifdef VCS_ME16_STAMPS
+    if (MODE == kMe16Search && lane == 0 && cost_out)
+        for (int i = 0; i < 8; i++) cost_out[(size_t)blockIdx.x * 8 + i] = st_acc[i];
+#endif
 }
 
 // The fast kernel covers the reference's own parameters for block_size 16 on
@@ -360,8 +410,9 @@ inline size_t me_fast_sums_bytes(const Geom &g) {
 
 inline int me16_slots() {
     static const int slots = [] {
-        const char *e = getenv("VCS_ME16_SLOTS");  // tuning knob: 14 or 18
-        return (e && atoi(e) == 14) ? 14 : 18;
+        const char *e = getenv("VCS_ME16_SLOTS");  // tuning knob: 13, 14 or 18
+        const int v = e ? atoi(e) : 18;
+        return (v == 13 || v == 14) ? v : 18;
     }();
     return slots;
 }
@@ -381,7 +432,7 @@ inline int me16_grid(int cus, long long total) {
 inline int launch_me_fast_sums(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                                uint32_t *sums) {
     dim3 gd(me16_grid(cus, g.N)), block(64);
-    if (me16_slots() == 14)
+    if (me16_slots() != 18)
         hipLaunchKernelGGL((k_me16<14, kMe16Sums>), gd, block, 0, stream, ref, ref, (size_t)0, g,
                            g.N, sums, (int16_t *)nullptr, (uint32_t *)nullptr,
                            (unsigned long long *)nullptr);
@@ -400,12 +451,50 @@ inline int launch_me_fast(const Geom &g, hipStream_t stream, int cus, const uint
     const long long total = (long long)g.N * n;
     if (total > 0x7FFFFFFF) return -1;
     dim3 gd(me16_grid(cus, total)), block(64);
-    if (me16_slots() == 14)
-        hipLaunchKernelGGL((k_me16<14, kMe16Search>), gd, block, 0, stream, ref, curs, stride, g,
-                           (int)total, sums, mv, ns, cost);
-    else
-        hipLaunchKernelGGL((k_me16<18, kMe16Search>), gd, block, 0, stream, ref, curs, stride, g,
-                           (int)total, sums, mv, ns, cost);
+#ifdef VCS_ME16_STAMPS
+    static unsigned long long *dbg = nullptr;
+    if (!dbg) hipMalloc(&dbg, sizeof(unsigned long long) * 8 * 65536);
+    hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * gd.x, stream);
+    cost = dbg;
+#endif
+    static const bool prefetch = [] {
+        const char *e = getenv("VCS_ME16_PREFETCH");  // tuning knob: 0 = no register prefetch
+        return !(e && e[0] == '0');
+    }();
+#define VCS_ME16_LAUNCH(S, P)                                                                  \
+    hipLaunchKernelGGL((k_me16<S, kMe16Search, P>), gd, block, 0, stream, ref, curs, stride, g, \
+                       (int)total, sums, mv, ns, cost)
+    const int sl = me16_slots();
+    if (prefetch) {
+        if (sl == 13) VCS_ME16_LAUNCH(13, true); else if (sl == 14) VCS_ME16_LAUNCH(14, true);
+        else VCS_ME16_LAUNCH(18, true);
+    } else {
+        if (sl == 13) VCS_ME16_LAUNCH(13, false); else if (sl == 14) VCS_ME16_LAUNCH(14, false);
+        else VCS_ME16_LAUNCH(18, false);
+    }
+#undef VCS_ME16_LAUNCH
+#ifdef VCS_ME16_STAMPS
+    {
+        static int calls = 0;
+        if (++calls == 3) {  // a warm launch
+            hipStreamSynchronize(stream);
+            std::vector<unsigned long long> h(8 * gd.x);
+            hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+            double acc[8] = {0};
+            for (unsigned w = 0; w < gd.x; w++)
+                for (int i = 0; i < 8; i++) acc[i] += (double)h[w * 8 + i];
+            double tot = 0;
+            for (int i = 0; i < 6; i++) tot += acc[i];
+            const char *nm[6] = {"issue next loads", "static test", "park window", "row loop",
+                                 "reduce+store", "reg hand-over"};
+            const double blocks = (double)total;
+            for (int i = 0; i < 6; i++)
+                fprintf(stderr, "[me16 stamps] %-18s %6.1f %%  %8.0f ticks/block\n", nm[i],
+                        100.0 * acc[i] / tot, acc[i] / blocks);
+            fprintf(stderr, "[me16 stamps] total %.0f ticks/block (s_memtime, 100 MHz?)\n", tot / blocks);
+        }
+    }
+#endif
     return 0;
 }
 

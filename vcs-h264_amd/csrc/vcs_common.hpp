@@ -18,10 +18,27 @@ struct Geom {
 };
 
 // ---- wave64 reductions ---------------------------------------------------
+// DPP inside each 16-lane row (4 VALU ops, no LDS crossbar round trips), then
+// four v_readlane + scalar ops across the rows.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_u32<0xB1>(v);   // quad_perm:[1,0,3,2]
+    v += dpp_u32<0x4E>(v);   // quad_perm:[2,3,0,1]
+    v += dpp_u32<0x141>(v);  // row_half_mirror
+    v += dpp_u32<0x140>(v);  // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x141>(v));
+    v = min(v, dpp_u32<0x140>(v));
+    return min(min((uint32_t)__builtin_amdgcn_readlane(v, 0), (uint32_t)__builtin_amdgcn_readlane(v, 16)),
+               min((uint32_t)__builtin_amdgcn_readlane(v, 32), (uint32_t)__builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
 #pragma unroll
