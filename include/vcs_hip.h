@@ -152,6 +152,16 @@ int vcs_dev_ptr(vcs_ctx *ctx, int which, void **ptr, size_t *bytes);
  * vcs_dev_ptr(ctx, 0, ...) by a collective.                                 */
 int vcs_ref_written(vcs_ctx *ctx);
 
+/* GPU-side ordering against a foreign HIP stream (the stream torch / RCCL
+ * collectives run on), without host synchronisation:
+ *   vcs_stream_wait:   work enqueued on the context's stream after this call
+ *                      waits for everything enqueued on `foreign_stream` so far;
+ *   vcs_stream_signal: work enqueued on `foreign_stream` after this call waits
+ *                      for everything enqueued on the context's stream so far.
+ * `foreign_stream` is a hipStream_t (NULL = the legacy default stream).        */
+int vcs_stream_wait(vcs_ctx *ctx, void *foreign_stream);
+int vcs_stream_signal(vcs_ctx *ctx, void *foreign_stream);
+
 /* ---- measurement ------------------------------------------------------- */
 /* With timing on, every kernel launch is bracketed by HIP events on the
  * context's stream; vcs_timing() synchronises and returns, per VCS_T_* slot,

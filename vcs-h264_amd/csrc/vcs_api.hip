@@ -58,6 +58,7 @@ struct vcs_ctx {
     int16_t *g_mv = nullptr;
     uint32_t *g_ns = nullptr;
     void *g_planes = nullptr;
+    hipEvent_t xev = nullptr;  // cross-stream ordering with a foreign (torch / RCCL) stream
     // timing
     bool timing = false;
     std::vector<EvPair> pending;
@@ -433,6 +434,7 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     CREATE_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
     if (c->cus < 1) c->cus = 1;
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&c->xev, hipEventDisableTiming));
     // the reference carries slack rows: k_me16 fetches its window 64 rows deep
     // without clamping at the bottom edge (the extra rows are never used)
     CREATE_TRY(hipMalloc(&c->d_ref, c->Fs + me_fast_ref_slack(g)));
@@ -474,6 +476,7 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     hipFree(c->d_coords); hipFree(c->d_cost); hipFree(c->d_ns); hipFree(c->d_planes);
     hipFree(c->d_DQ);
     hipFree(c->d_sums);
+    if (c->xev) hipEventDestroy(c->xev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return VCS_OK;
@@ -798,6 +801,22 @@ int vcs_ref_written(vcs_ctx *c) {
     if (rc) return rc;
     c->ref_valid = true;
     c->sums_valid = false;
+    return VCS_OK;
+}
+
+int vcs_stream_wait(vcs_ctx *c, void *foreign_stream) {
+    int rc = use(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->xev, (hipStream_t)foreign_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->xev, 0));
+    return VCS_OK;
+}
+
+int vcs_stream_signal(vcs_ctx *c, void *foreign_stream) {
+    int rc = use(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->xev, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent((hipStream_t)foreign_stream, c->xev, 0));
     return VCS_OK;
 }
 

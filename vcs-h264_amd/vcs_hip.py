@@ -56,6 +56,8 @@ SIGNATURES = {
     "vcs_dev_ptr": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.POINTER(_vp),
                                    ctypes.POINTER(ctypes.c_size_t)]),
     "vcs_ref_written": (ctypes.c_int, [_c_ctx]),
+    "vcs_stream_wait": (ctypes.c_int, [_c_ctx, _vp]),
+    "vcs_stream_signal": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_timing_enable": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
     "vcs_timing_reset": (ctypes.c_int, [_c_ctx]),
     "vcs_timing": (ctypes.c_int, [_c_ctx, _f64p, _u64p, ctypes.c_int]),
@@ -306,6 +308,14 @@ class Context:
 
     def ref_written(self):
         self._ck(self._lib.vcs_ref_written(self._h))
+
+    def stream_wait(self, foreign_stream):
+        """Our stream waits for `foreign_stream` (a hipStream_t as int; 0 = default)."""
+        self._ck(self._lib.vcs_stream_wait(self._h, ctypes.c_void_p(int(foreign_stream) or None)))
+
+    def stream_signal(self, foreign_stream):
+        """`foreign_stream` waits for our stream."""
+        self._ck(self._lib.vcs_stream_signal(self._h, ctypes.c_void_p(int(foreign_stream) or None)))
 
     # -- measurement --------------------------------------------------------
     def timing_enable(self, on=True):
