@@ -152,6 +152,17 @@ int vcs_dev_ptr(vcs_ctx *ctx, int which, void **ptr, size_t *bytes);
  * vcs_dev_ptr(ctx, 0, ...) by a collective.                                 */
 int vcs_ref_written(vcs_ctx *ctx);
 
+/* ---- intra prediction (next row N1; BASELINE config 5) ------------------ */
+/* IntraframeCompression/intraframe.py: luma4x4 (:24-151), luma16x16 (:153-225)
+ * and chroma8x8 (:228-317) with the predictors of intramodes.py.  Planes are
+ * H x W uint8 with H, W the context's frame size (multiples of 4 / 16 / 8);
+ * outputs are float64 like the reference's: residual, prediction (H x W) and
+ * the mode map ((H/bs) x (W/bs)).                                            */
+int vcs_intra_luma4x4(vcs_ctx *ctx, const uint8_t *Y, double *res, double *pred, double *modes);
+int vcs_intra_luma16x16(vcs_ctx *ctx, const uint8_t *Y, double *res, double *pred, double *modes);
+int vcs_intra_chroma8x8(vcs_ctx *ctx, const uint8_t *Cr, const uint8_t *Cb, double *crres,
+                        double *crpred, double *cbres, double *cbpred, double *modes);
+
 /* GPU-side ordering against a foreign HIP stream (the stream torch / RCCL
  * collectives run on), without host synchronisation:
  *   vcs_stream_wait:   work enqueued on the context's stream after this call

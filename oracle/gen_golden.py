@@ -263,10 +263,56 @@ def g6_real_small():
     save("real_small.npz", **d)
 
 
+def g7_intra_small():
+    """Intra prediction.  intraframe.py runs its demo at import
+    (line 391), so only its definitions -- source lines 1-318, the three
+    functions luma4x4 / luma16x16 / chroma8x8 -- are executed, in place, from
+    /root/reference; intramodes.py is imported normally."""
+    import warnings
+    idir = os.path.join(REF, "IntraframeCompression")
+    sys.path.insert(0, idir)
+    src = open(os.path.join(idir, "intraframe.py")).read().split("\n")
+    ns = {"__name__": "ref_intraframe_defs"}
+    exec(compile("\n".join(src[:318]), os.path.join(idir, "intraframe.py"), "exec"), ns)
+    import cv2 as standin
+    rng = np.random.default_rng(11)
+    H, W = 64, 96
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = (np.stack([120 + 60 * np.sin(xx / 11.0) + 30 * np.cos(yy / 5.0),
+                     90 + 80 * np.cos((xx + yy) / 9.0), 140 + 70 * np.sin(yy / 7.0)], axis=-1)
+           + rng.integers(-25, 26, (H, W, 3))).clip(0, 255).astype(np.uint8)
+    img[16:32, 32:64] = rng.integers(0, 256, (16, 32, 3))      # full-range texture
+    img[40:48, :16] = 255                                      # exercises the 3*x//4 wrap
+    img[48:56, 80:] = 0
+    ycc = standin.cvtColor(img, standin.COLOR_BGR2YCR_CB)
+    Y, Cr, Cb = [np.ascontiguousarray(ycc[..., k]) for k in range(3)]
+    d = dict(Y=Y, Cr=Cr, Cb=Cb)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # the reference's uint8 scalar overflow warnings
+        r, p, m = ns["luma4x4"](Y)
+        d.update(l4_res=r, l4_pred=p, l4_modes=m)
+        r, p, m = ns["luma16x16"](Y)
+        d.update(l16_res=r, l16_pred=p, l16_modes=m)
+        rr, rp, br, bp, m = ns["chroma8x8"](Cr, Cb)
+        d.update(c8_crres=rr, c8_crpred=rp, c8_cbres=br, c8_cbpred=bp, c8_modes=m)
+        # a second, fully random plane set: every mode and every edge case gets hit
+        Y2 = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+        Cr2 = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+        Cb2 = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+        d.update(Y2=Y2, Cr2=Cr2, Cb2=Cb2)
+        r, p, m = ns["luma4x4"](Y2)
+        d.update(l4_res2=r, l4_pred2=p, l4_modes2=m)
+        r, p, m = ns["luma16x16"](Y2)
+        d.update(l16_res2=r, l16_pred2=p, l16_modes2=m)
+        rr, rp, br, bp, m = ns["chroma8x8"](Cr2, Cb2)
+        d.update(c8_crres2=rr, c8_crpred2=rp, c8_cbres2=br, c8_cbpred2=bp, c8_modes2=m)
+    save("intra_small.npz", **d)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_me_small, g2_me_edges, g4_dct_small, g5_codec_small, g6_real_small,
-               g3_me_1080p):
+               g7_intra_small, g3_me_1080p):
         if only and fn.__name__.split("_")[0] not in only:
             continue
         print(fn.__name__)

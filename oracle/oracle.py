@@ -221,6 +221,47 @@ def round_i16(planes):
     return out
 
 
+def intra_luma4x4(Y):
+    """intraframe.py:24-151 -> (res, pred, modes) float64."""
+    Y = _c(Y, np.uint8)
+    H, W = Y.shape
+    res, pred = np.zeros((H, W)), np.zeros((H, W))
+    modes = np.zeros((H // 4, W // 4))
+    rc = lib().vcso_intra_luma4x4(_p(Y, _u8p), H, W, _p(res, _f64p), _p(pred, _f64p),
+                                  _p(modes, _f64p))
+    if rc:
+        raise ValueError("luma4x4 needs H, W multiples of 4 and W >= 8")
+    return res, pred, modes
+
+
+def intra_luma16x16(Y):
+    """intraframe.py:153-225."""
+    Y = _c(Y, np.uint8)
+    H, W = Y.shape
+    res, pred = np.zeros((H, W)), np.zeros((H, W))
+    modes = np.zeros((H // 16, W // 16))
+    rc = lib().vcso_intra_luma16x16(_p(Y, _u8p), H, W, _p(res, _f64p), _p(pred, _f64p),
+                                    _p(modes, _f64p))
+    if rc:
+        raise ValueError("luma16x16 needs H, W multiples of 16")
+    return res, pred, modes
+
+
+def intra_chroma8x8(Cr, Cb):
+    """intraframe.py:228-317 -> (Crres, Crpred, Cbres, Cbpred, modes)."""
+    Cr = _c(Cr, np.uint8)
+    Cb = _c(Cb, np.uint8)
+    H, W = Cr.shape
+    out = [np.zeros((H, W)) for _ in range(4)]
+    modes = np.zeros((H // 8, W // 8))
+    rc = lib().vcso_intra_chroma8x8(_p(Cr, _u8p), _p(Cb, _u8p), H, W, _p(out[0], _f64p),
+                                    _p(out[1], _f64p), _p(out[2], _f64p), _p(out[3], _f64p),
+                                    _p(modes, _f64p))
+    if rc:
+        raise ValueError("chroma8x8 needs H, W multiples of 8")
+    return out[0], out[1], out[2], out[3], modes
+
+
 def set_threads(n):
     """OpenMP thread count for the cpu_baseline timing (bench.py)."""
     os.environ["OMP_NUM_THREADS"] = str(n)

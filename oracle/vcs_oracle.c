@@ -377,3 +377,227 @@ int vcso_decode_p(const int16_t *mv, const double *planes, const uint8_t *ref,
 void vcso_round_i16(const double *in, size_t n, int16_t *out) {
     for (size_t i = 0; i < n; i++) out[i] = (int16_t)nearbyint(in[i]);
 }
+
+/* ======================================================================== */
+/* Intra prediction (BASELINE config 5):                   */
+/* /root/reference/IntraframeCompression/intraframe.py + intramodes.py.      */
+/* Every value the reference computes here is integer-valued (floor          */
+/* divisions of integers held in float64), so the restatement is integer     */
+/* arithmetic; outputs are float64 like the reference's.  NumPy 2 (NEP 50)   */
+/* quirks that change results are marked QUIRK.                              */
+/* ------------------------------------------------------------------------ */
+static inline int fdiv(int a, int b) { /* Python floor division, b > 0 */
+    int q = a / b;
+    return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+/* 3*x//4 (intramodes.py:42,135): QUIRK -- when x is an element of a uint8
+ * array, 3*x is evaluated in uint8 and wraps mod 256 (NEP 50); when the
+ * neighbour row is one of the float64 stand-ins (np.ones(4)*...) it does not. */
+static inline int three_q(int x, int is_u8) { return is_u8 ? ((3 * x) & 255) / 4 : (3 * x) / 4; }
+
+/* The nine 4x4 predictors, intramodes.py:7-143.  u8 flags: which neighbour
+ * arrays are real uint8 views (vs float64 stand-ins).                       */
+static void pred4x4(int mode, int ul, const int *u, const int *ur, const int *l,
+                    int u_u8, int ur_u8, int l_u8, int p[4][4]) {
+    int r, c;
+    switch (mode) {
+    case 0: for (r = 0; r < 4; r++) for (c = 0; c < 4; c++) p[r][c] = u[c]; break;   /* :7-11  */
+    case 1: for (r = 0; r < 4; r++) for (c = 0; c < 4; c++) p[r][c] = l[r]; break;   /* :13-17 */
+    case 2: {                                                                        /* :19-23 */
+        int s = 0; /* QUIRK: u + l on two uint8 arrays wraps per element (:21) */
+        for (c = 0; c < 4; c++) s += (u_u8 && l_u8) ? ((u[c] + l[c]) & 255) : (u[c] + l[c]);
+        for (r = 0; r < 4; r++) for (c = 0; c < 4; c++) p[r][c] = s / 8;
+        break; }
+    case 3: {                                                                        /* :25-43 */
+        int a = u[0]/4 + u[1]/2 + u[2]/4, b = u[1]/4 + u[2]/2 + u[3]/4;
+        int d = u[2]/4 + u[3]/2 + ur[0]/4, e = u[3]/4 + ur[0]/2 + ur[1]/4;
+        int f = ur[0]/4 + ur[1]/2 + ur[2]/4, g = ur[1]/4 + ur[2]/2 + ur[3]/4;
+        int h = ur[2]/4 + three_q(ur[3], ur_u8);
+        p[0][0]=a; p[0][1]=b; p[1][0]=b; p[0][2]=d; p[1][1]=d; p[2][0]=d;
+        p[0][3]=e; p[1][2]=e; p[2][1]=e; p[3][0]=e; p[1][3]=f; p[2][2]=f; p[3][1]=f;
+        p[2][3]=g; p[3][2]=g; p[3][3]=h;
+        break; }
+    case 4: {                                                                        /* :45-63 */
+        int a = u[1]/4 + u[2]/2 + u[3]/4, b = u[0]/4 + u[1]/2 + u[2]/4;
+        int d = ul/4 + u[0]/2 + u[1]/4, e = ul/4 + u[0]/2 + l[0]/4;
+        int f = u[0]/4 + l[0]/2 + l[1]/4, g = l[0]/4 + l[1]/2 + l[2]/4, h = l[1]/4 + l[2]/2 + l[3]/4;
+        p[0][3]=a; p[0][2]=b; p[1][3]=b; p[0][1]=d; p[1][2]=d; p[2][3]=d;
+        p[0][0]=e; p[1][1]=e; p[2][2]=e; p[3][3]=e; p[1][0]=f; p[2][1]=f; p[3][2]=f;
+        p[2][0]=g; p[3][1]=g; p[3][0]=h;
+        break; }
+    case 5: {                                                                        /* :65-83 */
+        p[0][0] = ul/2 + u[0]/2;              p[2][1] = p[0][0];
+        p[0][1] = u[0]/2 + u[1]/2;            p[2][2] = p[0][1];
+        p[0][2] = u[1]/2 + u[2]/2;            p[2][3] = p[0][2];
+        p[0][3] = u[2]/2 + u[3]/2;
+        p[1][0] = u[0]/4 + ul/2 + l[0]/4;     p[3][1] = p[1][0];
+        p[1][1] = ul/4 + u[0]/2 + u[1]/4;     p[3][2] = p[1][1];
+        p[1][2] = u[0]/4 + u[1]/2 + u[2]/4;   p[3][3] = p[1][2];
+        p[1][3] = u[1]/4 + u[2]/2 + u[3]/4;
+        p[2][0] = ul/4 + l[0]/2 + l[1]/4;
+        p[3][0] = l[0]/4 + l[1]/2 + l[2]/4;
+        break; }
+    case 6: {                                                                        /* :85-103 */
+        p[0][0] = ul/2 + l[0]/2;              p[1][2] = p[0][0];
+        p[0][1] = u[0]/4 + ul/2 + l[0]/4;     p[1][3] = p[0][1];
+        p[0][2] = ul/4 + u[0]/2 + u[1]/4;
+        p[0][3] = u[0]/4 + u[1]/2 + u[2]/4;
+        p[1][0] = l[0]/2 + l[1]/2;            p[2][2] = p[1][0];
+        p[1][1] = ul/4 + l[1]/2 + l[2]/4;     p[2][3] = p[1][1];
+        p[2][0] = l[1]/2 + l[2]/2;            p[3][2] = p[2][0];
+        p[2][1] = l[0]/4 + l[1]/2 + l[2]/4;   p[3][3] = p[2][1];
+        p[3][0] = l[2]/2 + l[3]/2;
+        p[3][1] = l[1]/4 + l[2]/2 + l[3]/4;
+        break; }
+    case 7: {                                                                        /* :105-123 */
+        p[0][0] = u[0]/2 + u[1]/2;
+        p[0][1] = u[1]/2 + u[2]/2;            p[2][0] = p[0][1];
+        p[0][2] = u[2]/2 + u[3]/2;            p[2][1] = p[0][2];
+        p[0][3] = u[3]/2 + ur[0]/2;           p[2][2] = p[0][3];
+        p[2][3] = ur[0]/2 + ur[1]/2;
+        p[1][0] = u[0]/4 + u[1]/2 + u[2]/4;
+        p[1][1] = u[1]/4 + u[2]/2 + u[3]/4;   p[3][0] = p[1][1];
+        p[1][2] = u[2]/4 + u[3]/2 + ur[0]/4;  p[3][1] = p[1][2];
+        p[1][3] = u[3]/4 + ur[0]/2 + ur[1]/4; p[3][2] = p[1][3];
+        p[3][3] = ur[0]/4 + ur[1]/2 + ur[2]/4;
+        break; }
+    default: {                                                                       /* :125-143 */
+        p[0][0] = l[0]/2 + l[1]/2;
+        p[0][1] = l[0]/4 + l[1]/2 + l[2]/4;
+        p[0][2] = l[1]/2 + l[2]/2;            p[1][0] = p[0][2];
+        p[0][3] = l[1]/4 + l[2]/2 + l[3]/4;   p[1][1] = p[0][3];
+        p[1][2] = l[2]/2 + l[3]/2;            p[2][0] = p[1][2];
+        p[1][3] = l[2]/4 + three_q(l[3], l_u8); p[2][1] = p[1][3];
+        p[3][0] = p[2][2] = p[2][3] = p[3][1] = p[3][2] = p[3][3] = l[3];
+        break; }
+    }
+}
+
+/* intraframe.py:24-151 (luma4x4).  Y: H x W uint8 (multiples of 4, W >= 8).
+ * res, pred: H x W float64; modes: (H/4) x (W/4) float64.
+ * Neighbour availability (:38-54): the aliased `available` rows (:30) make no
+ * visible difference in raster order; what matters is the CASE ORDER: top row
+ * -> left only; left column -> up and up-right only; last column -> no
+ * up-right (replicated Y[i-1, j+3] as float64, :69-70).                      */
+int vcso_intra_luma4x4(const uint8_t *Y, int H, int W, double *res, double *pred, double *modes) {
+    if (H % 4 || W % 4 || W < 8) return -1;
+    const int rows = H / 4, cols = W / 4;
+#pragma omp parallel for schedule(static)
+    for (int bi = 0; bi < rows; bi++)
+        for (int bj = 0; bj < cols; bj++) {
+            const int i = bi * 4, j = bj * 4;
+            int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            if (bi == 0 && bj == 0) { }
+            else if (bi == 0) s3 = 1;
+            else if (bj == 0) { s1 = 1; s2 = 1; }
+            else if (bj + 1 == cols) { s0 = 1; s1 = 1; s3 = 1; }
+            else { s0 = s1 = s2 = s3 = 1; }
+            int ul = s0 ? Y[(i - 1) * W + j - 1] : 128, u[4], ur[4], l[4];
+            for (int k = 0; k < 4; k++) {
+                u[k] = s1 ? Y[(i - 1) * W + j + k] : 128;
+                ur[k] = s2 ? Y[(i - 1) * W + j + 4 + k] : (s1 ? Y[(i - 1) * W + j + 3] : 128);
+                l[k] = s3 ? Y[(i + k) * W + j - 1] : 128;
+            }
+            int best = 16 * 255, bmode = 0, bp[4][4] = {{0}}; /* :79-81 */
+            for (int m = 0; m < 9; m++) {
+                int p[4][4], d = 0;
+                pred4x4(m, ul, u, ur, l, s1, s2, s3, p);
+                for (int r = 0; r < 4; r++)
+                    for (int c = 0; c < 4; c++) d += abs(p[r][c] - (int)Y[(i + r) * W + j + c]);
+                if (d < best) { best = d; bmode = m; memcpy(bp, p, sizeof bp); } /* strict < */
+            }
+            for (int r = 0; r < 4; r++)
+                for (int c = 0; c < 4; c++) {
+                    pred[(i + r) * W + j + c] = bp[r][c];
+                    res[(i + r) * W + j + c] = (int)Y[(i + r) * W + j + c] - bp[r][c]; /* :146 */
+                }
+            modes[bi * cols + bj] = bmode;
+        }
+    return 0;
+}
+
+/* intraframe.py:153-225 (luma16x16) with intramodes.py:145-161.             */
+int vcso_intra_luma16x16(const uint8_t *Y, int H, int W, double *res, double *pred, double *modes) {
+    if (H % 16 || W % 16) return -1;
+    const int rows = H / 16, cols = W / 16;
+#pragma omp parallel for schedule(static)
+    for (int bi = 0; bi < rows; bi++)
+        for (int bj = 0; bj < cols; bj++) {
+            const int i = bi * 16, j = bj * 16;
+            int s1 = 0, s2 = 0; /* u, l (ul is fetched but no predictor uses it) */
+            if (bi == 0 && bj == 0) { }
+            else if (bi == 0) s2 = 1;
+            else if (bj == 0) s1 = 1;
+            else { s1 = s2 = 1; }
+            int u[16], l[16], su = 0, sl = 0;
+            for (int k = 0; k < 16; k++) {
+                u[k] = s1 ? Y[(i - 1) * W + j + k] : 128; su += u[k];
+                l[k] = s2 ? Y[(i + k) * W + j - 1] : 128; sl += l[k];
+            }
+            const int dc = (su + sl) / 32; /* :159 np.sum of uint8 does not wrap */
+            int d[3] = {0, 0, 0};
+            for (int r = 0; r < 16; r++)
+                for (int c = 0; c < 16; c++) {
+                    int y = Y[(i + r) * W + j + c];
+                    d[0] += abs(u[c] - y); d[1] += abs(l[r] - y); d[2] += abs(dc - y);
+                }
+            int best = 16 * 16 * 255, bmode = -1; /* :196 */
+            for (int m = 0; m < 3; m++) if (d[m] < best) { best = d[m]; bmode = m; }
+            for (int r = 0; r < 16; r++)
+                for (int c = 0; c < 16; c++) {
+                    int p = bmode == 0 ? u[c] : bmode == 1 ? l[r] : bmode == 2 ? dc : 0;
+                    pred[(i + r) * W + j + c] = p;
+                    res[(i + r) * W + j + c] = (int)Y[(i + r) * W + j + c] - p;
+                }
+            modes[bi * cols + bj] = bmode < 0 ? 0 : bmode;
+        }
+    return 0;
+}
+
+/* intraframe.py:228-317 (chroma8x8).  QUIRK (:266): the upper neighbour of the
+ * Cb block is read from Cbres -- the RESIDUAL being built -- not from Cb, which
+ * makes every block depend on the one above it (serial down each column).   */
+int vcso_intra_chroma8x8(const uint8_t *Cr, const uint8_t *Cb, int H, int W, double *crres,
+                         double *crpred, double *cbres, double *cbpred, double *modes) {
+    if (H % 8 || W % 8) return -1;
+    const int rows = H / 8, cols = W / 8;
+#pragma omp parallel for schedule(static)
+    for (int bj = 0; bj < cols; bj++)
+        for (int bi = 0; bi < rows; bi++) {
+            const int i = bi * 8, j = bj * 8;
+            int s1 = 0, s2 = 0;
+            if (bi == 0 && bj == 0) { }
+            else if (bi == 0) s2 = 1;
+            else if (bj == 0) s1 = 1;
+            else { s1 = s2 = 1; }
+            int ur[8], ub[8], lr[8], lb[8], sur = 0, sub = 0, slr = 0, slb = 0;
+            for (int k = 0; k < 8; k++) {
+                ur[k] = s1 ? Cr[(i - 1) * W + j + k] : 128;
+                ub[k] = s1 ? (int)cbres[(i - 1) * W + j + k] : 128; /* :266 */
+                lr[k] = s2 ? Cr[(i + k) * W + j - 1] : 128;
+                lb[k] = s2 ? Cb[(i + k) * W + j - 1] : 128;
+                sur += ur[k]; sub += ub[k]; slr += lr[k]; slb += lb[k];
+            }
+            const int dcr = fdiv(sur + slr, 16), dcb = fdiv(sub + slb, 16); /* intramodes.py:177 */
+            int d[3] = {0, 0, 0};
+            for (int r = 0; r < 8; r++)
+                for (int c = 0; c < 8; c++) {
+                    int yr = Cr[(i + r) * W + j + c], yb = Cb[(i + r) * W + j + c];
+                    d[0] += abs(ur[c] - yr) + abs(ub[c] - yb);
+                    d[1] += abs(lr[r] - yr) + abs(lb[r] - yb);
+                    d[2] += abs(dcr - yr) + abs(dcb - yb);
+                }
+            int best = 2 * 8 * 8 * 255, bmode = -1; /* :280 */
+            for (int m = 0; m < 3; m++) if (d[m] < best) { best = d[m]; bmode = m; }
+            for (int r = 0; r < 8; r++)
+                for (int c = 0; c < 8; c++) {
+                    int pr = bmode == 0 ? ur[c] : bmode == 1 ? lr[r] : bmode == 2 ? dcr : 0;
+                    int pb = bmode == 0 ? ub[c] : bmode == 1 ? lb[r] : bmode == 2 ? dcb : 0;
+                    size_t o = (size_t)(i + r) * W + j + c;
+                    crpred[o] = pr; crres[o] = (int)Cr[o] - pr;
+                    cbpred[o] = pb; cbres[o] = (int)Cb[o] - pb;
+                }
+            modes[bi * cols + bj] = bmode < 0 ? 0 : bmode;
+        }
+    return 0;
+}

@@ -381,3 +381,42 @@ def test_gop_encoder_single_rank(vh, oracle):
         assert np.array_equal(mv[k], omv) and ns[k] == ons
         assert np.array_equal(enc.backend.planes(k), oplanes)
     enc.backend.close()
+
+
+@pytest.mark.parametrize("sfx", ["", "2"])
+def test_golden_intra(vh, sfx):
+    """Next row N1 / BASELINE config 5: intra prediction vs the reference's outputs."""
+    g = load_golden("intra_small.npz")
+    Y, Cr, Cb = g["Y" + sfx], g["Cr" + sfx], g["Cb" + sfx]
+    sys_path = __import__("sys").path
+    idir = __import__("os").path.join(__import__("conftest").PKG, "IntraframeCompression")
+    if idir not in sys_path:
+        sys_path.insert(0, idir)
+    import intraframe as I
+    res, pred, modes = I.luma4x4(Y)
+    assert np.array_equal(modes, g["l4_modes" + sfx])
+    assert np.array_equal(pred, g["l4_pred" + sfx]) and np.array_equal(res, g["l4_res" + sfx])
+    res, pred, modes = I.luma16x16(Y)
+    assert np.array_equal(modes, g["l16_modes" + sfx])
+    assert np.array_equal(pred, g["l16_pred" + sfx]) and np.array_equal(res, g["l16_res" + sfx])
+    crres, crpred, cbres, cbpred, modes = I.chroma8x8(Cr, Cb)
+    assert np.array_equal(modes, g["c8_modes" + sfx])
+    assert np.array_equal(crpred, g["c8_crpred" + sfx]) and np.array_equal(crres, g["c8_crres" + sfx])
+    assert np.array_equal(cbpred, g["c8_cbpred" + sfx]) and np.array_equal(cbres, g["c8_cbres" + sfx])
+
+
+def test_intra_1080p_vs_oracle(vh, oracle):
+    """Config 5 shape: a 1080p I frame resized to multiples of 16 (1920 x 1072)."""
+    rng = np.random.default_rng(4)
+    H, W = 1072, 1920
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = (128 + 70 * np.sin(xx / 23.0) * np.cos(yy / 17.0)).astype(np.int16)
+    planes = [np.clip(base + rng.integers(-30, 31, (H, W)), 0, 255).astype(np.uint8) for _ in range(3)]
+    with vh.Context(H, W, 16) as c:
+        for bs, fn in ((4, oracle.intra_luma4x4), (16, oracle.intra_luma16x16)):
+            got, want = c.intra_luma(planes[0], bs), fn(planes[0])
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b)
+        got, want = c.intra_chroma(planes[1], planes[2]), oracle.intra_chroma8x8(planes[1], planes[2])
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)

@@ -116,3 +116,22 @@ def test_colour_roundtrip_properties(oracle):
     assert np.array_equal(ycc[..., 0], grey[..., 0])
     assert (ycc[..., 1:] == 128).all()
     assert np.array_equal(oracle.ycrcb2bgr(ycc), grey)
+
+
+@pytest.mark.parametrize("sfx", ["", "2"])
+def test_intra_small(oracle, sfx):
+    """Intra prediction: integer restatement vs the reference's
+    luma4x4 / luma16x16 / chroma8x8, NumPy-2 uint8 quirks included."""
+    g = load_golden("intra_small.npz")
+    Y, Cr, Cb = g["Y" + sfx], g["Cr" + sfx], g["Cb" + sfx]
+    res, pred, modes = oracle.intra_luma4x4(Y)
+    assert np.array_equal(modes, g["l4_modes" + sfx])
+    assert np.array_equal(pred, g["l4_pred" + sfx]) and np.array_equal(res, g["l4_res" + sfx])
+    assert len(np.unique(modes)) >= 8  # the fixture exercises (nearly) every mode
+    res, pred, modes = oracle.intra_luma16x16(Y)
+    assert np.array_equal(modes, g["l16_modes" + sfx])
+    assert np.array_equal(pred, g["l16_pred" + sfx]) and np.array_equal(res, g["l16_res" + sfx])
+    crres, crpred, cbres, cbpred, modes = oracle.intra_chroma8x8(Cr, Cb)
+    assert np.array_equal(modes, g["c8_modes" + sfx])
+    assert np.array_equal(crpred, g["c8_crpred" + sfx]) and np.array_equal(crres, g["c8_crres" + sfx])
+    assert np.array_equal(cbpred, g["c8_cbpred" + sfx]) and np.array_equal(cbres, g["c8_cbres" + sfx])

@@ -12,6 +12,7 @@
 
 #include "../../include/vcs_hip.h"
 #include "dct_kernels.hpp"
+#include "intra_kernels.hpp"
 #include "me_fast.hpp"
 #include "me_kernels.hpp"
 
@@ -48,6 +49,7 @@ struct vcs_ctx {
     unsigned long long *d_cost = nullptr;
     uint32_t *d_ns = nullptr;
     void *d_planes = nullptr;
+    double *d_intra = nullptr;  // intra prediction outputs: 4 planes + modes, float64
     double *d_DQ = nullptr;  // D[64] + Q[192] + 1/Q[192]
     double hDQ[448];
     bool fastdiv = false;    // Q table admits the 3-FMA exact division
@@ -476,6 +478,7 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     hipFree(c->d_coords); hipFree(c->d_cost); hipFree(c->d_ns); hipFree(c->d_planes);
     hipFree(c->d_DQ);
     hipFree(c->d_sums);
+    hipFree(c->d_intra);
     if (c->xev) hipEventDestroy(c->xev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -801,6 +804,76 @@ int vcs_ref_written(vcs_ctx *c) {
     if (rc) return rc;
     c->ref_valid = true;
     c->sums_valid = false;
+    return VCS_OK;
+}
+
+// ---- intra prediction -----------------------------------------
+static int ensure_intra(vcs_ctx *c) {
+    if (c->d_intra) return VCS_OK;
+    const size_t hw = (size_t)c->g.H * c->g.W;
+    HIP_TRY(c, hipMalloc(&c->d_intra, sizeof(double) * (4 * hw + hw / 16 + 64)));
+    return VCS_OK;
+}
+
+static int intra_luma(vcs_ctx *c, int bs, const uint8_t *Y, double *res, double *pred,
+                      double *modes) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!Y || !res || !pred || !modes) return fail(c, VCS_E_ARG, "null pointer");
+    const int H = c->g.H, W = c->g.W;
+    if (H % bs || W % bs || W < 8)
+        return fail(c, VCS_E_ARG, "intra luma %dx%d needs plane sizes that are multiples of %d "
+                    "(the reference resizes to multiples of 16 first, intraframe.py:324)", bs, bs, bs);
+    if ((rc = ensure_intra(c))) return rc;
+    const size_t hw = (size_t)H * W, nm = (size_t)(H / bs) * (W / bs);
+    double *dres = c->d_intra, *dpred = c->d_intra + hw, *dmodes = c->d_intra + 4 * hw;
+    HIP_TRY(c, hipMemcpyAsync(c->d_a, Y, hw, hipMemcpyHostToDevice, c->stream));
+    EvPair ev;
+    if ((rc = t_begin(c, VCS_T_AUX, &ev))) return rc;
+    if (bs == 4)
+        hipLaunchKernelGGL(k_intra_luma4, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_a, H, W, dres, dpred, dmodes);
+    else
+        hipLaunchKernelGGL(k_intra_luma16, dim3((unsigned)nm), dim3(64), 0, c->stream, c->d_a, H, W,
+                           dres, dpred, dmodes);
+    if ((rc = t_end(c, &ev))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(res, dres, hw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(pred, dpred, hw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(modes, dmodes, nm * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_intra_luma4x4(vcs_ctx *c, const uint8_t *Y, double *res, double *pred, double *modes) {
+    return intra_luma(c, 4, Y, res, pred, modes);
+}
+int vcs_intra_luma16x16(vcs_ctx *c, const uint8_t *Y, double *res, double *pred, double *modes) {
+    return intra_luma(c, 16, Y, res, pred, modes);
+}
+
+int vcs_intra_chroma8x8(vcs_ctx *c, const uint8_t *Cr, const uint8_t *Cb, double *crres,
+                        double *crpred, double *cbres, double *cbpred, double *modes) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!Cr || !Cb || !crres || !crpred || !cbres || !cbpred || !modes)
+        return fail(c, VCS_E_ARG, "null pointer");
+    const int H = c->g.H, W = c->g.W;
+    if (H % 8 || W % 8) return fail(c, VCS_E_ARG, "intra chroma 8x8 needs multiples of 8");
+    if ((rc = ensure_intra(c))) return rc;
+    const size_t hw = (size_t)H * W, nm = (size_t)(H / 8) * (W / 8);
+    double *d0 = c->d_intra, *dmodes = c->d_intra + 4 * hw;
+    HIP_TRY(c, hipMemcpyAsync(c->d_a, Cr, hw, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_a + hw, Cb, hw, hipMemcpyHostToDevice, c->stream));
+    EvPair ev;
+    if ((rc = t_begin(c, VCS_T_AUX, &ev))) return rc;
+    hipLaunchKernelGGL(k_intra_chroma8, dim3(W / 8), dim3(64), 0, c->stream, c->d_a, c->d_a + hw, H,
+                       W, d0, d0 + hw, d0 + 2 * hw, d0 + 3 * hw, dmodes);
+    if ((rc = t_end(c, &ev))) return rc;
+    double *outs[4] = {crres, crpred, cbres, cbpred};
+    for (int k = 0; k < 4; k++)
+        HIP_TRY(c, hipMemcpyAsync(outs[k], d0 + k * hw, hw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(modes, dmodes, nm * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VCS_OK;
 }
 

@@ -56,6 +56,9 @@ SIGNATURES = {
     "vcs_dev_ptr": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.POINTER(_vp),
                                    ctypes.POINTER(ctypes.c_size_t)]),
     "vcs_ref_written": (ctypes.c_int, [_c_ctx]),
+    "vcs_intra_luma4x4": (ctypes.c_int, [_c_ctx, _u8p, _f64p, _f64p, _f64p]),
+    "vcs_intra_luma16x16": (ctypes.c_int, [_c_ctx, _u8p, _f64p, _f64p, _f64p]),
+    "vcs_intra_chroma8x8": (ctypes.c_int, [_c_ctx, _u8p, _u8p, _f64p, _f64p, _f64p, _f64p, _f64p]),
     "vcs_stream_wait": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_signal": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_timing_enable": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
@@ -260,6 +263,32 @@ class Context:
         self._ck(self._lib.vcs_decode_p(self._h, mv.ctypes.data_as(_i16p), pp,
                                         out.ctypes.data_as(_u8p)))
         return out
+
+    # -- intra prediction (next row N1) ---------------------------------------
+    def _plane(self, a, name):
+        a = np.asarray(a)
+        if a.dtype != np.uint8 or a.shape != (self.H, self.W):
+            raise ValueError("%s must be a uint8 plane of shape (%d, %d)" % (name, self.H, self.W))
+        return np.ascontiguousarray(a)
+
+    def intra_luma(self, Y, bs):
+        Y = self._plane(Y, "Y")
+        res, pred = np.zeros((self.H, self.W)), np.zeros((self.H, self.W))
+        modes = np.zeros((self.H // bs, self.W // bs))
+        fn = self._lib.vcs_intra_luma4x4 if bs == 4 else self._lib.vcs_intra_luma16x16
+        self._ck(fn(self._h, Y.ctypes.data_as(_u8p), res.ctypes.data_as(_f64p),
+                    pred.ctypes.data_as(_f64p), modes.ctypes.data_as(_f64p)))
+        return res, pred, modes
+
+    def intra_chroma(self, Cr, Cb):
+        Cr, Cb = self._plane(Cr, "Cr"), self._plane(Cb, "Cb")
+        outs = [np.zeros((self.H, self.W)) for _ in range(4)]
+        modes = np.zeros((self.H // 8, self.W // 8))
+        self._ck(self._lib.vcs_intra_chroma8x8(self._h, Cr.ctypes.data_as(_u8p),
+                                               Cb.ctypes.data_as(_u8p),
+                                               *[o.ctypes.data_as(_f64p) for o in outs],
+                                               modes.ctypes.data_as(_f64p)))
+        return outs[0], outs[1], outs[2], outs[3], modes
 
     # -- GOP path -----------------------------------------------------------
     def gop_reserve(self, n_slots, with_decode=False):
