@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--bs", type=int, default=16, help="motion block size (window = 2*bs)")
     ap.add_argument("--frames", type=int, default=29, help="P frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-decode", action="store_true",
+                    help="also time the decode kernel over the GOP (reported next to the line)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed (RCCL) code path even with one rank")
     args = ap.parse_args()
@@ -101,7 +103,7 @@ def main():
     N, F = ctx.N, ctx.F
     # this rank's slice of the (long) GOP; synthetic, deterministic
     ref, frames = synth_gop(H, W, n, seed=1234, first=1 + rank * n)
-    ctx.gop_reserve(n)
+    ctx.gop_reserve(n, with_decode=args.with_decode)
     ctx.gop_upload(0, frames)
     if use_dist:
         ptr, nb = ctx.dev_ptr(0)
@@ -223,6 +225,20 @@ def main():
                                        "fill_write_only": round(ctx.measure_fill_bw(1 << 28, 5), 0)}
         except vcs_hip.VcsError:
             pass
+        if args.with_decode:
+            # second line of SURVEY 8d: dequantise + IDCT + colour + MC-add over the same GOP
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            for _ in range(5):
+                ctx.gop_decode(0, n)
+            ms2, l2 = ctx.timing()
+            ctx.timing_enable(False)
+            dec_ms = ms2[vcs_hip.T_DEC] / max(1, int(l2[vcs_hip.T_DEC]))
+            alg = (9 * F + 4 * N + F) * n  # planes + ref + vectors in, frame out
+            out["decode"] = {"kernel": "k_idct<residual>", "avg_launch_ms": round(dec_ms, 4),
+                             "achieved_gbs": round(alg / (dec_ms * 1e-3) / 1e9, 1),
+                             "encode_plus_decode_macroblocks_per_ms":
+                                 round(n * N / (dt / args.steps * 1e3 + dec_ms), 1)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W, bs, ref, frames)
         else:

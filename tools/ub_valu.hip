@@ -24,6 +24,15 @@ __global__ __launch_bounds__(64) void k(uint32_t *out, unsigned long long *cyc, 
                 if (OP == 2) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
                 if (OP == 3) asm volatile("v_sad_u8 %0, %1, 0, %0" : "+v"(a[i]) : "v"(b));
                 if (OP == 4) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+                if (OP == 6) asm volatile("v_and_or_b32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 7) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[i]));
+                if (OP == 8) asm volatile("v_add3_u32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 9) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 10) asm volatile("v_perm_b32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 11) asm volatile("v_alignbit_b32 %0, %1, %0, 7" : "+v"(a[i]) : "v"(b));
+                if (OP == 12) asm volatile("v_lshl_or_b32 %0, %1, 1, %0" : "+v"(a[i]) : "v"(b));
+                if (OP == 14) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (OP == 15) asm volatile("v_msad_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
                 if (OP == 5) {  // the row-loop mix, dependent chain per element: lerp -> and -> bcnt
                     uint32_t t;
                     asm volatile("v_lerp_u8 %0, %1, %2, %3" : "=v"(t) : "v"(a[i]), "v"(b), "v"(c));
@@ -63,7 +72,18 @@ void run(const char *name, int blocks, int per_it) {
 }
 
 int main() {
-    for (int blocks : {1024, 2048, 4096}) {
+    for (int blocks : {2048}) {
+        run<6>("v_and_or_b32", blocks, 1);
+        run<7>("v_lshrrev_b32", blocks, 1);
+        run<8>("v_add3_u32", blocks, 1);
+        run<9>("v_bfi_b32", blocks, 1);
+        run<10>("v_perm_b32", blocks, 1);
+        run<11>("v_alignbit_b32", blocks, 1);
+        run<12>("v_lshl_or_b32", blocks, 1);
+        run<14>("v_mad_u32_u24", blocks, 1);
+        run<15>("v_msad_u8", blocks, 1);
+    }
+    for (int blocks : {2048}) {
         run<0>("v_lerp_u8", blocks, 1);
         run<1>("v_and_b32", blocks, 1);
         run<2>("v_bcnt_u32_b32", blocks, 1);

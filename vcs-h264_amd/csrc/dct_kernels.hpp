@@ -188,35 +188,47 @@ __global__ __launch_bounds__(64) void k_idct(
     const uint8_t *__restrict__ ref, const int16_t *__restrict__ mvs, Geom g,
     const double *__restrict__ DQ, uint8_t *__restrict__ outs, size_t out_stride) {
     __shared__ double s_t[8 * kTilePad];
+    __shared__ double s_q[24 * kOutPad];  // Q[3][8][8], rows padded to 9
     const int lane = threadIdx.x;
     const int t = lane >> 3, j = lane & 7;
     const int groups_x = (g.W + 63) >> 6;
     const int ty = blockIdx.x / groups_x, gx = blockIdx.x - ty * groups_x;
     const int f = blockIdx.y;
     const int x = gx * 64 + lane;
-    const bool live = x < g.W;
+    const int xl = min(x, g.W - 1);  // lanes past the frame edge: clamped loads, no stores
     const size_t plane = (size_t)g.H * g.W;
     const typename CoeffT<CM>::type *__restrict__ in = planes + (size_t)f * planes_stride;
     const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
     const double *__restrict__ D = DQ;
     const double *__restrict__ Q = DQ + 64;
 
+    // ---- every global load up front, branch-free ----------------------------------
+    for (int e = lane; e < 192; e += 64) s_q[(e >> 3) * kOutPad + (e & 7)] = Q[e];
+    double X[3][8];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            X[ch][k] = (double)in[ch * plane + (size_t)(ty * 8 + k) * g.W + xl];
+    // stage-2 ownership: row j of tile t -> 8 pixels starting at column xo
+    const int y = ty * 8 + j, xo = min(gx * 64 + t * 8, g.W - 8);
+    uint32_t pp[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) pp[jj] = MODE == 1 ? pred_px(ref, mv, g, y, xo + jj) : 0u;
+    wave_lds_fence();
+
     int ycc[3][8];  // row i = j of the tile, 8 pixels, after stage 2
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-        double X[8];  // column j of the dequantised tile (:86 np.multiply)
+        // dequantise (:86 np.multiply), column j of the tile
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            double v = 0.0;
-            if (live) v = (double)in[ch * plane + (size_t)(ty * 8 + k) * g.W + x];
-            X[k] = v * Q[ch * 64 + k * 8 + j];
-        }
+        for (int k = 0; k < 8; k++) X[ch][k] = X[ch][k] * s_q[(ch * 8 + k) * kOutPad + j];
         // stage 1: T = D^T * X (:119)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) acc = __builtin_fma(D[k * 8 + i], X[k], acc);
+            for (int k = 0; k < 8; k++) acc = __builtin_fma(D[k * 8 + i], X[ch][k], acc);
             s_t[t * kTilePad + i * 8 + j] = acc;
         }
         wave_lds_fence();
@@ -233,22 +245,25 @@ __global__ __launch_bounds__(64) void k_idct(
             ycc[ch][jj] = ((int)acc + 128) & 255;
         }
     }
-    if (!live) return;
-    const int y = ty * 8 + j, xo = gx * 64 + t * 8;
-    uint8_t *o = outs + (size_t)f * out_stride + (size_t)y * g.pitch + (size_t)(3 * xo);
+    if (gx * 64 + t * 8 >= g.W) return;
+    // 8 pixels = 24 bytes, packed into three 8-byte stores (24*t is 8-byte aligned)
+    uint8_t b[24];
 #pragma unroll
     for (int jj = 0; jj < 8; jj++) {
         int B, G, R;
         ycc2bgr(ycc[0][jj], ycc[1][jj], ycc[2][jj], B, G, R);  // :92
-        if (MODE == 1) {  // decoder.py:57 img + decompressed, uint8 wrap
-            const uint32_t p = pred_px(ref, mv, g, y, xo + jj);
-            B = (B + (int)(p & 255)) & 255;
-            G = (G + (int)((p >> 8) & 255)) & 255;
-            R = (R + (int)((p >> 16) & 255)) & 255;
-        }
-        o[3 * jj + 0] = (uint8_t)B;
-        o[3 * jj + 1] = (uint8_t)G;
-        o[3 * jj + 2] = (uint8_t)R;
+        const uint32_t p = pp[jj];                             // decoder.py:57 uint8 wrap add
+        b[3 * jj + 0] = (uint8_t)(B + (int)(p & 255));
+        b[3 * jj + 1] = (uint8_t)(G + (int)((p >> 8) & 255));
+        b[3 * jj + 2] = (uint8_t)(R + (int)((p >> 16) & 255));
+    }
+    uint2 *o = (uint2 *)(outs + (size_t)f * out_stride + (size_t)y * g.pitch + (size_t)(3 * xo));
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        uint2 v;
+        v.x = b[8 * q] | (b[8 * q + 1] << 8) | (b[8 * q + 2] << 16) | ((uint32_t)b[8 * q + 3] << 24);
+        v.y = b[8 * q + 4] | (b[8 * q + 5] << 8) | (b[8 * q + 6] << 16) | ((uint32_t)b[8 * q + 7] << 24);
+        o[q] = v;
     }
 }
 
