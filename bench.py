@@ -165,7 +165,7 @@ def main():
         # algorithmic HBM bytes per macroblock: ME reads cur + ref and
         # writes the vectors; the tail reads cur + ref + vectors, writes 3 f64 planes
         per_mb = {vcs_hip.T_ME: (2 * F + 4 * N) / N, vcs_hip.T_ENC_TAIL: (10 * F + 4 * N) / N}
-        names = {vcs_hip.T_ME: "k_me16" if bs == 16 else "k_me_generic",
+        names = {vcs_hip.T_ME: "k_me16" if bs == 16 else "k_me8" if bs == 8 else "k_me_generic",
                  vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
         # PMC-measured HBM bytes per launch of the same workload (profiles/hbm_traffic.json,
         # produced by profiles/collect.sh; FETCH_SIZE doubled per the gfx950 correction)

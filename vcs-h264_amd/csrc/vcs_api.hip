@@ -14,6 +14,7 @@
 #include "dct_kernels.hpp"
 #include "intra_kernels.hpp"
 #include "me_fast.hpp"
+#include "me_fast8.hpp"
 #include "me_kernels.hpp"
 
 using namespace vcs;
@@ -39,6 +40,7 @@ struct vcs_ctx {
     size_t me_lds = 0;     // dynamic LDS of the generic ME kernel
     bool ref_valid = false;
     bool me_fast_ok = false;
+    bool me_fast8_ok = false;
     uint32_t *d_sums = nullptr;  // k_me16: per-reference sum(r) table
     bool sums_valid = false;
     int cus = 256;         // compute units of the device
@@ -131,6 +133,7 @@ int refresh_me_geometry(vcs_ctx *c) {
     // VCS_ME_GENERIC=1 forces the generic kernel (A/B measurements, debugging)
     const char *force = getenv("VCS_ME_GENERIC");
     c->me_fast_ok = me_fast_supported(g) && !(force && force[0] == '1');
+    c->me_fast8_ok = me_fast8_supported(g) && !(force && force[0] == '1');
     return VCS_OK;
 }
 
@@ -205,6 +208,14 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
             c->sums_valid = true;
         }
         rc = launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
+        if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
+    } else if (c->me_fast8_ok && !force_generic) {
+        if (!c->sums_valid) {
+            launch_me_fast8_sums(c->g, c->stream, c->cus, ref, c->d_sums);
+            HIP_TRY(c, hipGetLastError());
+            c->sums_valid = true;
+        }
+        rc = launch_me_fast8(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
     } else {
         switch (c->g.bs) {
