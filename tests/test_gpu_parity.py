@@ -420,3 +420,57 @@ def test_intra_1080p_vs_oracle(vh, oracle):
         got, want = c.intra_chroma(planes[1], planes[2]), oracle.intra_chroma8x8(planes[1], planes[2])
         for a, b in zip(got, want):
             assert np.array_equal(a, b)
+
+
+def test_empty_and_tiny_frames(vh, oracle):
+    """Frames smaller than one motion block (N = 0) and frames too narrow for the
+    specialised kernels."""
+    rng = np.random.default_rng(12)
+    with vh.Context(8, 8, 16) as c:  # no full block at all
+        ref = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+        cur = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+        c.set_ref(ref)
+        mv, ns = c.me(cur)
+        assert mv.shape == (0, 2) and ns == 0
+        mv, planes, res, ns = c.encode_p(cur, want_planes=True, want_res=True)
+        assert np.array_equal(res, cur)  # prediction is all zero (motion.py:45-46)
+        assert np.array_equal(planes, oracle.compress(cur))
+        assert np.array_equal(c.decode_p(mv, planes), oracle.decompress(planes))
+    for H, W, bs in [(16, 16, 16), (16, 24, 16), (32, 28, 16), (8, 12, 8), (24, 16, 8)]:
+        ref = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        cur = np.roll(ref, (1, 2), axis=(0, 1))
+        with vh.Context(H, W, bs) as c:
+            c.set_ref(ref)
+            mv, ns, cost = c.me(cur, want_cost=True)
+            omv, ons, ocost = oracle.me(cur, ref, bs, want_cost=True)
+            assert np.array_equal(mv, omv) and ns == ons and np.array_equal(cost, ocost), (H, W, bs)
+
+
+def test_4k_frame_vs_oracle(vh, oracle):
+    """BASELINE config 4 shape (3840 x 2160): largest frame of the configs."""
+    from synth import synth_v1
+    ref, cur = synth_v1(2160, 3840, seed=4)
+    for bs in (16, 8):
+        with vh.Context(2160, 3840, bs) as c:
+            c.set_ref(ref)
+            mv, ns = c.me(cur)
+            omv, ons = oracle.me(cur, ref, bs)
+            assert np.array_equal(mv, omv) and ns == ons
+    with vh.Context(2160, 3840, 16) as c:
+        c.set_ref(ref)
+        mv, planes, _, _ = c.encode_p(cur)
+        _, oplanes, _ = oracle.encode_p(cur, ref, 16)
+        assert np.array_equal(planes, oplanes)
+
+
+def test_static_heavy_content(vh, oracle):
+    """Real video is mostly static blocks: the early-out path at 1080p."""
+    from synth import synth_static
+    ref, cur = synth_static(1080, 1920, seed=2, bs=16, frac=0.7)
+    for bs in (16, 8):
+        with vh.Context(1080, 1920, bs) as c:
+            c.set_ref(ref)
+            mv, ns = c.me(cur)
+            omv, ons = oracle.me(cur, ref, bs)
+            assert np.array_equal(mv, omv) and ns == ons
+            assert ns > 0.3 * len(mv)
