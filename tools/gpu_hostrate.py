@@ -1,6 +1,6 @@
 """PCIe-inclusive rate of the single-frame (host buffer) API at 1080p, for DESIGN.md."""
 import os, sys, time, io, contextlib
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "vcs-h264_amd"), os.path.join(ROOT, "vcs-h264_amd", "InterframeCompression")]
 import numpy as np
 import vcs_hip

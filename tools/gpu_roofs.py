@@ -1,5 +1,5 @@
 import sys, os
-sys.path[:0] = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "vcs-h264_amd")]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vcs-h264_amd")]
 import vcs_hip
 c = vcs_hip.Context(1080, 1920, 16)
 for nb in (1 << 28, 1 << 30, 3 << 29):
