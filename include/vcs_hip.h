@@ -127,6 +127,20 @@ int vcs_encode_p(vcs_ctx *ctx, const uint8_t *cur_bgr, int16_t *mv_out,
 int vcs_decode_p(vcs_ctx *ctx, const int16_t *mv, const void *planes,
                  uint8_t *bgr_out);
 
+/* ---- HBM-resident coefficient planes (next row N3) ---------------------- */
+/* Encoder._process_P_frame / Decoder._reconstruct_P_frame with the planes of
+ * Frame.r (encoder.py:66, decoder.py:55) left in HBM behind an opaque handle:
+ * only the motion vectors (and, on decode, the frame) cross PCIe; the planes
+ * are downloaded on demand.  A handle belongs to the device of its context
+ * and must be freed with vcs_store_free.                                    */
+typedef struct vcs_planes vcs_planes;
+int vcs_store_encode_p(vcs_ctx *ctx, const uint8_t *cur_bgr, int16_t *mv_out,
+                       uint32_t *n_static, vcs_planes **handle_out);
+int vcs_store_planes(vcs_ctx *ctx, const vcs_planes *h, void *planes_out);
+int vcs_store_decode_p(vcs_ctx *ctx, const int16_t *mv, const vcs_planes *h,
+                       uint8_t *bgr_out);
+int vcs_store_free(vcs_ctx *ctx, vcs_planes *h);
+
 /* ---- batched, HBM-resident GOP path ------------------------------------ */
 /* All P frames of a GOP depend only on the raw I frame (encoder.py:51-52), so
  * a whole GOP is one launch chain.  Slots 0..n-1 hold P frames; outputs stay

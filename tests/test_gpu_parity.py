@@ -474,3 +474,29 @@ def test_static_heavy_content(vh, oracle):
             omv, ons = oracle.me(cur, ref, bs)
             assert np.array_equal(mv, omv) and ns == ons
             assert ns > 0.3 * len(mv)
+
+
+def test_resident_planes_dropin(vh, capsys):
+    """Next row N3: Frame.r left in HBM; Decoder decodes straight from it; the
+    lazy view still behaves like the reference's list of three float64 planes."""
+    import encoder as E
+    import decoder as D
+    g = load_golden("codec_small.npz")
+    frames = g["frames"]
+    H, W = frames.shape[1:3]
+    enc = E.Encoder(pattern=["I", "P", "P"], shape=[H, W], block_size=8, with_DCT=True,
+                    resident=True)
+    for n in range(len(frames)):
+        enc.encode_frame(frames[n], n)
+    dec = D.Decoder(encoded_frames=enc.encoded_frames, fps=25.0, shape=[H, W],
+                    ref_frames=enc.ref_frames, block_size=8, with_DCT=True, sink=[].append)
+    for n, fr in enumerate(enc.encoded_frames):
+        if fr.t != "P":
+            continue
+        assert isinstance(fr.r, vh.ResidentPlanes) and fr.r._host is None  # nothing downloaded
+        assert np.array_equal(np.array(fr.mv), g["dct_mv_%d" % n])
+        assert np.array_equal(dec._reconstruct_P_frame(fr, True), g["dct_full_%d" % n])
+        assert fr.r._host is None                                         # ... still nothing
+        assert len(fr.r) == 3 and np.array_equal(np.stack(list(fr.r)), g["dct_r_%d" % n])
+        assert np.array_equal(fr.r[1], g["dct_r_%d" % n][1])
+    capsys.readouterr()

@@ -28,3 +28,19 @@ with contextlib.redirect_stdout(io.StringIO()):
         enc.encode_frame(frames[k], k + 1)
     dt = (time.perf_counter() - t0) / n
 print("drop-in Encoder.encode_frame (Python lists, float64): %.2f ms/frame = %.0f macroblocks/ms" % (dt * 1e3, N / dt / 1e3))
+import decoder as D
+enc = E.Encoder(pattern=["I"] + ["P"] * 29, shape=[H, W], block_size=16, with_DCT=True, dct_block_size=8, resident=True)
+with contextlib.redirect_stdout(io.StringIO()):
+    enc.encode_frame(ref, 0); enc.encode_frame(frames[0], 1)
+    t0 = time.perf_counter()
+    for k in range(n):
+        enc.encode_frame(frames[k], k + 2)
+    dt = (time.perf_counter() - t0) / n
+    dec = D.Decoder(encoded_frames=enc.encoded_frames, fps=25.0, shape=[H, W], ref_frames=enc.ref_frames,
+                    block_size=16, with_DCT=True, dct_block_size=8, sink=[].append)
+    dec._reconstruct_P_frame(enc.encoded_frames[1], True)
+    t0 = time.perf_counter()
+    for fr in enc.encoded_frames[2:]:
+        dec._reconstruct_P_frame(fr, True)
+    dd = (time.perf_counter() - t0) / n
+print("drop-in Encoder(resident=True).encode_frame: %.2f ms/frame = %.0f macroblocks/ms; Decoder from HBM: %.2f ms/frame" % (dt * 1e3, N / dt / 1e3, dd * 1e3))

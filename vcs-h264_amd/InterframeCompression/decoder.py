@@ -10,7 +10,7 @@ import numpy as np
 
 from DCTcompressor import DCTCompressor
 from motion import MotionProcessor, _as_frame
-from _runtime import ensure_q, ensure_ref
+from _runtime import ensure_q, ensure_ref, vcs_hip
 
 WRITE_REF_FRAMES = True
 
@@ -86,7 +86,11 @@ class Decoder:
         num_static = int(np.count_nonzero((mv == 0).all(axis=1)))
         print("There are", num_static, "static blocks out of", len(mv), "blocks")
         print("begin decompression")
-        planes = np.stack([np.asarray(p) for p in cur_frame.r])
-        frame = ctx.decode_p(mv.astype(np.int16), planes)
+        r = cur_frame.r
+        if isinstance(r, vcs_hip.ResidentPlanes) and r.resident and r._ctx is ctx:
+            frame = ctx.store_decode_p(mv.astype(np.int16), r)  # planes never left HBM
+        else:
+            planes = np.stack([np.asarray(p) for p in r])
+            frame = ctx.decode_p(mv.astype(np.int16), planes)
         print("decompression finished")
         return frame

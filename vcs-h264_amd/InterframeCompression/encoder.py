@@ -8,8 +8,13 @@ separate host round trips; the stored Frame is identical to the reference's.
 Extension (keyword-only): `dct_block_size` -- the reference hands ONE
 block_size to both MotionProcessor and DCTCompressor (encoder.py:16-18), so
 with_DCT only works at 8; pass dct_block_size=8 to compose e.g. 16x16 motion
-blocks with the 8x8 DCT (the BASELINE workload).
+blocks with the 8x8 DCT (the BASELINE workload).  `resident=True` (or the
+environment variable VCS_RESIDENT=1, so that an unchanged main.py can opt in)
+leaves the coefficient planes of Frame.r in HBM: Frame.r is then a list-like
+view that downloads on first access, and the drop-in Decoder decodes straight
+from HBM -- the 8x-frame-size planes never cross PCIe.
 """
+import os
 import math
 
 import numpy as np
@@ -22,7 +27,8 @@ from _runtime import ensure_q, ensure_ref
 
 class Encoder:
 
-    def __init__(self, pattern, shape, block_size, with_DCT, *, dct_block_size=None, device=0):
+    def __init__(self, pattern, shape, block_size, with_DCT, *, dct_block_size=None, device=0,
+                 resident=None):
         self.ref_frames = []
         self.encoded_frames = []
         self.pattern = pattern
@@ -31,6 +37,7 @@ class Encoder:
         self.DCTCompressor = DCTCompressor(
             block_size=block_size if dct_block_size is None else dct_block_size, device=device)
         self.with_DCT = with_DCT
+        self.resident = (os.environ.get("VCS_RESIDENT") == "1") if resident is None else bool(resident)
 
     def encode_frame(self, input_frame, frame_num):
         print("Encoding new frame of index", frame_num)
@@ -64,15 +71,20 @@ class Encoder:
         ensure_ref(ctx, _as_frame(ref, mp.shape, "ref_frame"))
         if self.with_DCT:
             ensure_q(ctx, dc.Q, dc.coeff_mode)
-        mv, planes, res, n_static = ctx.encode_p(cur, want_planes=bool(self.with_DCT),
-                                                 want_res=not self.with_DCT)
+        keep = self.with_DCT and self.resident
+        if keep:
+            mv, planes, n_static = ctx.store_encode_p(cur)
+            res = None
+        else:
+            mv, planes, res, n_static = ctx.encode_p(cur, want_planes=bool(self.with_DCT),
+                                                     want_res=not self.with_DCT)
         mp.last_static_blocks = n_static
         print("Finished processing motion. Got motion vectors.")
         num_static = int(np.count_nonzero((mv == 0).all(axis=1)))
         print("There are", num_static, "static blocks out of", len(mv), "blocks")
         if self.with_DCT:
             print("begin compression")
-            r = [planes[0], planes[1], planes[2]]
+            r = planes if keep else [planes[0], planes[1], planes[2]]
         else:
             r = res
         return Frame("P", motion_vectors=mv.astype(np.int64).tolist(), residuals=r,

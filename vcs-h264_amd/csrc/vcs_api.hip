@@ -677,6 +677,107 @@ int vcs_decode_p(vcs_ctx *c, const int16_t *mv, const void *planes, uint8_t *bgr
     return VCS_OK;
 }
 
+// ---- HBM-resident coefficient planes (next row N3) ----------------------------
+// The float64 planes of a P frame are 8x the frame (49.8 MB at 1080p) and
+// dominate the PCIe time of the single-frame API.  These entry points leave them
+// in HBM behind an opaque handle: the encoder returns only the motion vectors,
+// the decoder consumes the handle directly, and the planes are downloaded only
+// if somebody actually looks at them.
+struct vcs_planes {
+    void *d = nullptr;
+    size_t bytes = 0;
+    int coeff_mode = 0;
+    int H = 0, W = 0;
+};
+
+int vcs_store_encode_p(vcs_ctx *c, const uint8_t *cur, int16_t *mv_out, uint32_t *n_static,
+                       vcs_planes **handle_out) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!cur || !mv_out || !handle_out) return fail(c, VCS_E_ARG, "null pointer");
+    *handle_out = nullptr;
+    if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
+    if ((rc = need_dct_geometry(c))) return rc;
+    vcs_planes *h = new (std::nothrow) vcs_planes();
+    if (!h) return fail(c, VCS_E_NOMEM, "out of host memory");
+    h->bytes = planes_bytes(c);
+    h->coeff_mode = c->coeff_mode;
+    h->H = c->g.H;
+    h->W = c->g.W;
+    hipError_t e = hipMalloc(&h->d, h->bytes + 64);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(c, VCS_E_NOMEM, "hipMalloc(planes): %s", hipGetErrorString(e));
+    }
+    const size_t N = c->g.N;
+    rc = VCS_OK;
+    hipError_t e2 = hipMemcpyAsync(c->d_cur, cur, c->F, hipMemcpyHostToDevice, c->stream);
+    if (e2 != hipSuccess) rc = fail(c, VCS_E_HIP, "upload: %s", hipGetErrorString(e2));
+    if (!rc) rc = launch_me(c, c->d_ref, c->d_cur, c->Fs, 1, c->d_mv, c->d_ns, nullptr);
+    if (!rc)
+        rc = N ? launch_fdct<1>(c, VCS_T_ENC_TAIL, c->d_cur, c->Fs, c->d_ref, c->d_mv, 1, h->d, 0)
+               : launch_fdct<0>(c, VCS_T_ENC_TAIL, c->d_cur, c->Fs, nullptr, nullptr, 1, h->d, 0);
+    uint32_t ns = 0;
+    if (!rc && N) {
+        e2 = hipMemcpyAsync(mv_out, c->d_mv, N * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&ns, c->d_ns, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e2 != hipSuccess) rc = fail(c, VCS_E_HIP, "download: %s", hipGetErrorString(e2));
+    }
+    e2 = hipStreamSynchronize(c->stream);
+    if (!rc && e2 != hipSuccess) rc = fail(c, VCS_E_HIP, "sync: %s", hipGetErrorString(e2));
+    if (rc) {
+        hipFree(h->d);
+        delete h;
+        return rc;
+    }
+    if (n_static) *n_static = ns;
+    *handle_out = h;
+    return VCS_OK;
+}
+
+static int check_handle(vcs_ctx *c, const vcs_planes *h) {
+    if (!h || !h->d) return fail(c, VCS_E_ARG, "null planes handle");
+    if (h->H != c->g.H || h->W != c->g.W || h->coeff_mode != c->coeff_mode)
+        return fail(c, VCS_E_ARG, "planes handle does not match this context (size / coeff_mode)");
+    return VCS_OK;
+}
+
+int vcs_store_planes(vcs_ctx *c, const vcs_planes *h, void *planes_out) {
+    int rc = use(c);
+    if (rc || (rc = check_handle(c, h))) return rc;
+    if (!planes_out) return fail(c, VCS_E_ARG, "null pointer");
+    HIP_TRY(c, hipMemcpyAsync(planes_out, h->d, h->bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_store_decode_p(vcs_ctx *c, const int16_t *mv, const vcs_planes *h, uint8_t *bgr_out) {
+    int rc = use(c);
+    if (rc || (rc = check_handle(c, h))) return rc;
+    if (!bgr_out || (c->g.N > 0 && !mv)) return fail(c, VCS_E_ARG, "null pointer");
+    if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
+    if ((rc = check_mv(c, mv, nullptr, c->g.N))) return rc;
+    const size_t N = c->g.N;
+    if (N) HIP_TRY(c, hipMemcpyAsync(c->d_mv, mv, N * 4, hipMemcpyHostToDevice, c->stream));
+    rc = N ? launch_idct<1>(c, VCS_T_DEC, h->d, 0, c->d_ref, c->d_mv, 1, c->d_a, c->Fs)
+           : launch_idct<0>(c, VCS_T_DEC, h->d, 0, nullptr, nullptr, 1, c->d_a, c->Fs);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(bgr_out, c->d_a, c->F, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_store_free(vcs_ctx *c, vcs_planes *h) {
+    if (!h) return VCS_OK;
+    if (c) {
+        hipSetDevice(c->device);
+        if (c->stream) hipStreamSynchronize(c->stream);
+    }
+    hipFree(h->d);
+    delete h;
+    return VCS_OK;
+}
+
 // ---- GOP path ------------------------------------------------------------
 int vcs_gop_reserve(vcs_ctx *c, int n_slots, int with_decode) {
     int rc = use(c);

@@ -45,6 +45,10 @@ SIGNATURES = {
     "vcs_decompress": (ctypes.c_int, [_c_ctx, _vp, _u8p]),
     "vcs_encode_p": (ctypes.c_int, [_c_ctx, _u8p, _i16p, _vp, _u8p, _u32p]),
     "vcs_decode_p": (ctypes.c_int, [_c_ctx, _i16p, _vp, _u8p]),
+    "vcs_store_encode_p": (ctypes.c_int, [_c_ctx, _u8p, _i16p, _u32p, ctypes.POINTER(_vp)]),
+    "vcs_store_planes": (ctypes.c_int, [_c_ctx, _vp, _vp]),
+    "vcs_store_decode_p": (ctypes.c_int, [_c_ctx, _i16p, _vp, _u8p]),
+    "vcs_store_free": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_gop_reserve": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
     "vcs_gop_upload": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _u8p]),
     "vcs_gop_encode": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
@@ -125,6 +129,49 @@ def _frame(a, shape=None, name="frame"):
     if shape is not None and tuple(a.shape) != tuple(shape):
         raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
     return np.ascontiguousarray(a)
+
+
+class ResidentPlanes:
+    """The three coefficient planes of one P frame, left in HBM (vcs_store_*).
+
+    Behaves like the reference's `[Y, Cr, Cb]` list of float64 arrays (len 3,
+    indexing, iteration); the 8x-frame-size download happens on first access
+    only.  The decoder consumes the HBM copy directly."""
+
+    def __init__(self, ctx, handle):
+        self._ctx, self._h, self._host = ctx, handle, None
+
+    def _planes(self):
+        if self._host is None:
+            c = self._ctx
+            out = np.zeros((3, c.H, c.W), c.coeff_dtype)
+            c._ck(c._lib.vcs_store_planes(c._h, self._h, out.ctypes.data_as(_vp)))
+            self._host = out
+        return self._host
+
+    def __len__(self):
+        return 3
+
+    def __getitem__(self, i):
+        return [self._planes()[0], self._planes()[1], self._planes()[2]][i]
+
+    def __iter__(self):
+        return iter([self._planes()[k] for k in range(3)])
+
+    @property
+    def resident(self):
+        return self._h is not None and bool(self._ctx._h.value)
+
+    def release(self):
+        if self._h is not None and getattr(self._ctx, "_h", None) is not None and self._ctx._h.value:
+            self._ctx._lib.vcs_store_free(self._ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class Context:
@@ -262,6 +309,26 @@ class Context:
         out = np.zeros(self.shape, np.uint8)
         self._ck(self._lib.vcs_decode_p(self._h, mv.ctypes.data_as(_i16p), pp,
                                         out.ctypes.data_as(_u8p)))
+        return out
+
+    # -- HBM-resident planes (next row N3) ------------------------------------
+    def store_encode_p(self, cur):
+        cur = _frame(cur, self.shape, "input frame")
+        mv = np.zeros((self.N, 2), np.int16)
+        ns = ctypes.c_uint32(0)
+        h = _vp()
+        self._ck(self._lib.vcs_store_encode_p(self._h, cur.ctypes.data_as(_u8p),
+                                              mv.ctypes.data_as(_i16p), ctypes.byref(ns),
+                                              ctypes.byref(h)))
+        return mv, ResidentPlanes(self, h), ns.value
+
+    def store_decode_p(self, mv, planes):
+        mv = np.ascontiguousarray(np.asarray(mv, np.int16).reshape(-1, 2))
+        if mv.shape[0] != self.N:
+            raise ValueError("expected %d motion vectors, got %d" % (self.N, mv.shape[0]))
+        out = np.zeros(self.shape, np.uint8)
+        self._ck(self._lib.vcs_store_decode_p(self._h, mv.ctypes.data_as(_i16p), planes._h,
+                                              out.ctypes.data_as(_u8p)))
         return out
 
     # -- intra prediction (next row N1) ---------------------------------------
