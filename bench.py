@@ -165,7 +165,7 @@ def main():
         # algorithmic HBM bytes per macroblock: ME reads cur + ref and
         # writes the vectors; the tail reads cur + ref + vectors, writes 3 f64 planes
         per_mb = {vcs_hip.T_ME: (2 * F + 4 * N) / N, vcs_hip.T_ENC_TAIL: (10 * F + 4 * N) / N}
-        names = {vcs_hip.T_ME: "k_me16" if bs == 16 else "k_me8" if bs == 8 else "k_me_generic",
+        names = {vcs_hip.T_ME: "k_me16r" if bs == 16 else "k_me8" if bs == 8 else "k_me_generic",
                  vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
         # PMC-measured HBM bytes per launch of the same workload (profiles/hbm_traffic.json,
         # produced by profiles/collect.sh; FETCH_SIZE doubled per the gfx950 correction)
@@ -208,7 +208,7 @@ def main():
             "roofline": roof(dom),
             "roofline_second_kernel": roof(other),
         }
-        if names[vcs_hip.T_ME] == "k_me16":
+        if names[vcs_hip.T_ME] == "k_me16r":
             # the motion search is bound by vector-ALU issue, not by HBM: say how close it
             # is to THAT roof (wave-instructions per launch from profiles/r01 PMC, 16-lane
             # SIMDs issue one wave64 instruction per 4 cycles)
@@ -216,7 +216,7 @@ def main():
             peak = 256 * 4 * 2.4e9 / 4
             me_ms = ms[vcs_hip.T_ME] / max(1, int(launches[vcs_hip.T_ME]))
             ach = valu_per_mb * n * N / (me_ms * 1e-3)
-            out["k_me16_valu_issue"] = {"achieved_ginst_s": round(ach / 1e9, 1),
+            out["k_me16r_valu_issue"] = {"achieved_ginst_s": round(ach / 1e9, 1),
                                         "peak_ginst_s": round(peak / 1e9, 1),
                                         "frac": round(ach / peak, 3),
                                         "valu_wave_insts_per_macroblock": valu_per_mb}

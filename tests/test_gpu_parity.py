@@ -500,3 +500,41 @@ def test_resident_planes_dropin(vh, capsys):
         assert len(fr.r) == 3 and np.array_equal(np.stack(list(fr.r)), g["dct_r_%d" % n])
         assert np.array_equal(fr.r[1], g["dct_r_%d" % n][1])
     capsys.readouterr()
+
+
+def test_gop_1080p_rolling_kernel(vh, oracle):
+    """13 frames at 1080p: enough column segments for the rolling-window kernel
+    (k_me16r) to be selected by default."""
+    from synth import synth_gop
+    H, W, n = 1080, 1920, 13
+    ref, frames = synth_gop(H, W, n, seed=77)
+    with vh.Context(H, W, 16) as c:
+        c.set_ref(ref)
+        c.gop_reserve(n)
+        c.gop_upload(0, frames)
+        c.gop_encode(0, n)
+        mv, ns = c.gop_get_mv(0, n)
+        for k in range(n):
+            omv, ons = oracle.me(frames[k], ref, 16)
+            assert np.array_equal(mv[k], omv), k
+            assert ns[k] == ons
+        _, oplanes, _ = oracle.encode_p(frames[n - 1], ref, 16)
+        assert np.array_equal(c.gop_get_planes(n - 1), oplanes)
+
+
+def test_forced_kernel_variants_subprocess():
+    """The same parity cases with the rolling-window kernel forced on small and
+    ragged frames (VCS_ME16_ROLL=2), with it disabled (=0), and with the generic
+    kernel forced (VCS_ME_GENERIC=1): one child process per setting."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = ("golden_me_small or golden_me_edges or me_vs_oracle_shapes or static_heavy or "
+           "4k_frame or empty_and_tiny or golden_real_small or gop_1080p_vs_oracle")
+    for env_add in ({"VCS_ME16_ROLL": "2"}, {"VCS_ME16_ROLL": "0"}, {"VCS_ME_GENERIC": "1"}):
+        env = dict(os.environ, **env_add)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
+                            "-m", "gpu", "-x", "-q", "-k", sel, "-p", "no:cacheprovider"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (env_add, r.stdout[-1500:], r.stderr[-500:])

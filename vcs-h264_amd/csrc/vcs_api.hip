@@ -15,6 +15,7 @@
 #include "intra_kernels.hpp"
 #include "me_fast.hpp"
 #include "me_fast8.hpp"
+#include "me_roll.hpp"
 #include "me_kernels.hpp"
 
 using namespace vcs;
@@ -42,6 +43,7 @@ struct vcs_ctx {
     bool me_fast_ok = false;
     bool me_fast8_ok = false;
     uint32_t *d_sums = nullptr;  // k_me16: per-reference sum(r) table
+    uint32_t *d_wq = nullptr;    // k_me16r: per-XCD work queue counters
     bool sums_valid = false;
     int cus = 256;         // compute units of the device
     // single-frame buffers
@@ -207,7 +209,9 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
             HIP_TRY(c, hipGetLastError());
             c->sums_valid = true;
         }
-        rc = launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
+        rc = me16r_worthwhile(c->g, c->cus, n)
+                 ? launch_me_roll(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost)
+                 : launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
     } else if (c->me_fast8_ok && !force_generic) {
         if (!c->sums_valid) {
@@ -453,6 +457,7 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     CREATE_TRY(hipMalloc(&c->d_ref, c->Fs + me_fast_ref_slack(g)));
     CREATE_TRY(hipMemset(c->d_ref, 0, c->Fs + me_fast_ref_slack(g)));
     CREATE_TRY(hipMalloc(&c->d_sums, me_fast_sums_bytes(g)));
+    CREATE_TRY(hipMalloc(&c->d_wq, 64));
     CREATE_TRY(hipMalloc(&c->d_cur, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_a, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_b, c->Fs));
@@ -489,6 +494,7 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     hipFree(c->d_coords); hipFree(c->d_cost); hipFree(c->d_ns); hipFree(c->d_planes);
     hipFree(c->d_DQ);
     hipFree(c->d_sums);
+    hipFree(c->d_wq);
     hipFree(c->d_intra);
     if (c->xev) hipEventDestroy(c->xev);
     if (c->stream) hipStreamDestroy(c->stream);
