@@ -212,7 +212,7 @@ def main():
             # the motion search is bound by vector-ALU issue, not by HBM: say how close it
             # is to THAT roof (wave-instructions per launch from profiles/r01 PMC, 16-lane
             # SIMDs issue one wave64 instruction per 4 cycles)
-            valu_per_mb = 1437.0
+            valu_per_mb = 1457.0
             peak = 256 * 4 * 2.4e9 / 4
             me_ms = ms[vcs_hip.T_ME] / max(1, int(launches[vcs_hip.T_ME]))
             ach = valu_per_mb * n * N / (me_ms * 1e-3)
