@@ -525,16 +525,19 @@ def test_gop_1080p_rolling_kernel(vh, oracle):
 def test_forced_kernel_variants_subprocess():
     """The same parity cases with the rolling-window kernel forced on small and
     ragged frames (VCS_ME16_ROLL=2), with it disabled (=0), and with the generic
-    kernel forced (VCS_ME_GENERIC=1): one child process per setting."""
+    kernel forced (VCS_ME_GENERIC=1), and the DCT cases with the exact 3-FMA
+    division (VCS_FAST_DIV=1): one child process per setting."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sel = ("golden_me_small or golden_me_edges or me_vs_oracle_shapes or static_heavy or "
            "4k_frame or empty_and_tiny or golden_real_small or gop_1080p_vs_oracle")
-    for env_add in ({"VCS_ME16_ROLL": "2"}, {"VCS_ME16_ROLL": "0"}, {"VCS_ME_GENERIC": "1"}):
+    dct = "golden_dct_small or encode_decode_vs_oracle or dct_extremes or coeff_modes"
+    for env_add, k in (({"VCS_ME16_ROLL": "2"}, sel), ({"VCS_ME16_ROLL": "0"}, sel),
+                       ({"VCS_ME_GENERIC": "1"}, sel), ({"VCS_FAST_DIV": "1"}, dct)):
         env = dict(os.environ, **env_add)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
-                            "-m", "gpu", "-x", "-q", "-k", sel, "-p", "no:cacheprovider"],
+                            "-m", "gpu", "-x", "-q", "-k", k, "-p", "no:cacheprovider"],
                            env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (env_add, r.stdout[-1500:], r.stderr[-500:])

@@ -235,9 +235,10 @@ __device__ __forceinline__ void me16_issue(const uint8_t *__restrict__ ref,
 
 // MODE kMe16Search: motion search of `total` work items (frame-major blocks).
 // MODE kMe16Sums:   fills sums[blk * 128 + cand] for the N blocks of `ref`.
-// SLOTS: 16-byte slots per LDS window row (18 = conflict-free, 14 = denser).
-template <int SLOTS, int MODE, bool PREFETCH = true>
-__global__ __launch_bounds__(64, PREFETCH ? 2 : 3) void k_me16(
+// SLOTS: 16-byte slots per LDS window row; 18 is the conflict-free pitch (13 and 14 were
+// measured: more waves per CU, but their 2-way bank conflicts cost more than that gains).
+template <int SLOTS, int MODE>
+__global__ __launch_bounds__(64, 2) void k_me16(
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
     Geom g, int total, uint32_t *__restrict__ sums, int16_t *__restrict__ mv,
     uint32_t *__restrict__ n_static, unsigned long long *__restrict__ cost_out) {
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(64, PREFETCH ? 2 : 3) void k_me16(
     Me16Offs O;
     me16_offsets(g, lane, O);
     Me16Regs A;
-    if (PREFETCH) me16_issue<MODE>(ref, curs, cur_stride, sums, g, w, lane, O, A);
+    me16_issue<MODE>(ref, curs, cur_stride, sums, g, w, lane, O, A);
 #ifdef VCS_ME16_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
@@ -270,10 +271,7 @@ __global__ __launch_bounds__(64, PREFETCH ? 2 : 3) void k_me16(
         // ---- prefetch the next block of this wave while this one is searched ------
         const int wn = w + nw;
         Me16Regs B;
-        if (PREFETCH)
-            me16_issue<MODE>(ref, curs, cur_stride, sums, g, min(wn, w_end - 1), lane, O, B);
-        else  // no register double-buffering: fewer VGPRs, a third wave per SIMD covers the latency
-            me16_issue<MODE>(ref, curs, cur_stride, sums, g, w, lane, O, A);
+        me16_issue<MODE>(ref, curs, cur_stride, sums, g, min(wn, w_end - 1), lane, O, B);
         ME16_STAMP(0);  // issue of the next block's loads
 
         const int f = w / g.N, blk = w - f * g.N;
@@ -387,7 +385,7 @@ __global__ __launch_bounds__(64, PREFETCH ? 2 : 3) void k_me16(
         }
         if (wn >= w_end) break;  // wave-uniform; every wave leaves after its share
         w = wn;
-        if (PREFETCH) A = B;
+        A = B;
         ME16_STAMP(5);  // register hand-over
     }
 #ifdef VCS_ME16_STAMPS
@@ -408,14 +406,6 @@ inline size_t me_fast_sums_bytes(const Geom &g) {
     return (size_t)(g.N > 0 ? g.N : 1) * kMe16SumStride * sizeof(uint32_t);
 }
 
-inline int me16_slots() {
-    static const int slots = [] {
-        const char *e = getenv("VCS_ME16_SLOTS");  // tuning knob: 13, 14 or 18
-        const int v = e ? atoi(e) : 18;
-        return (v == 13 || v == 14) ? v : 18;
-    }();
-    return slots;
-}
 inline int me16_grid(int cus, long long total) {
     static const int per_cu = [] {
         const char *e = getenv("VCS_ME16_WAVES_PER_CU");  // tuning knob
@@ -432,14 +422,8 @@ inline int me16_grid(int cus, long long total) {
 inline int launch_me_fast_sums(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                                uint32_t *sums) {
     dim3 gd(me16_grid(cus, g.N)), block(64);
-    if (me16_slots() != 18)
-        hipLaunchKernelGGL((k_me16<14, kMe16Sums>), gd, block, 0, stream, ref, ref, (size_t)0, g,
-                           g.N, sums, (int16_t *)nullptr, (uint32_t *)nullptr,
-                           (unsigned long long *)nullptr);
-    else
-        hipLaunchKernelGGL((k_me16<18, kMe16Sums>), gd, block, 0, stream, ref, ref, (size_t)0, g,
-                           g.N, sums, (int16_t *)nullptr, (uint32_t *)nullptr,
-                           (unsigned long long *)nullptr);
+    hipLaunchKernelGGL((k_me16<18, kMe16Sums>), gd, block, 0, stream, ref, ref, (size_t)0, g, g.N, sums,
+                       (int16_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr);
     return 0;
 }
 
@@ -457,22 +441,8 @@ inline int launch_me_fast(const Geom &g, hipStream_t stream, int cus, const uint
     hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * gd.x, stream);
     cost = dbg;
 #endif
-    static const bool prefetch = [] {
-        const char *e = getenv("VCS_ME16_PREFETCH");  // tuning knob: 0 = no register prefetch
-        return !(e && e[0] == '0');
-    }();
-#define VCS_ME16_LAUNCH(S, P)                                                                  \
-    hipLaunchKernelGGL((k_me16<S, kMe16Search, P>), gd, block, 0, stream, ref, curs, stride, g, \
-                       (int)total, sums, mv, ns, cost)
-    const int sl = me16_slots();
-    if (prefetch) {
-        if (sl == 13) VCS_ME16_LAUNCH(13, true); else if (sl == 14) VCS_ME16_LAUNCH(14, true);
-        else VCS_ME16_LAUNCH(18, true);
-    } else {
-        if (sl == 13) VCS_ME16_LAUNCH(13, false); else if (sl == 14) VCS_ME16_LAUNCH(14, false);
-        else VCS_ME16_LAUNCH(18, false);
-    }
-#undef VCS_ME16_LAUNCH
+    hipLaunchKernelGGL((k_me16<18, kMe16Search>), gd, block, 0, stream, ref, curs, stride, g,
+                       (int)total, sums, mv, ns, cost);
 #ifdef VCS_ME16_STAMPS
     {
         static int calls = 0;

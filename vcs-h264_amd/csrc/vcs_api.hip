@@ -43,7 +43,6 @@ struct vcs_ctx {
     bool me_fast_ok = false;
     bool me_fast8_ok = false;
     uint32_t *d_sums = nullptr;  // k_me16: per-reference sum(r) table
-    uint32_t *d_wq = nullptr;    // k_me16r: per-XCD work queue counters
     bool sums_valid = false;
     int cus = 256;         // compute units of the device
     // single-frame buffers
@@ -457,7 +456,6 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     CREATE_TRY(hipMalloc(&c->d_ref, c->Fs + me_fast_ref_slack(g)));
     CREATE_TRY(hipMemset(c->d_ref, 0, c->Fs + me_fast_ref_slack(g)));
     CREATE_TRY(hipMalloc(&c->d_sums, me_fast_sums_bytes(g)));
-    CREATE_TRY(hipMalloc(&c->d_wq, 64));
     CREATE_TRY(hipMalloc(&c->d_cur, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_a, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_b, c->Fs));
@@ -494,7 +492,6 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     hipFree(c->d_coords); hipFree(c->d_cost); hipFree(c->d_ns); hipFree(c->d_planes);
     hipFree(c->d_DQ);
     hipFree(c->d_sums);
-    hipFree(c->d_wq);
     hipFree(c->d_intra);
     if (c->xev) hipEventDestroy(c->xev);
     if (c->stream) hipStreamDestroy(c->stream);
