@@ -43,7 +43,6 @@ __device__ __forceinline__ uint32_t load_px(const uint8_t *p) {
     __builtin_memcpy(&v, p, 4);
     return v;
 }
-
 // a / b, correctly rounded, from y = RN(1 / b) in three fused operations
 // (Markstein): q = RN(a*y); r = RN(a - q*b) (exact); result = RN(q + r*y).
 // Valid when nothing over/underflows and b's significand is not all ones; the
@@ -74,26 +73,76 @@ __device__ __forceinline__ uint32_t pred_px(const uint8_t *__restrict__ ref,
     return (yc == y && xc == x) ? v : 0u;
 }
 
+
+// Strip (64 px x 8 rows) of frame f that this workgroup owns.  Workgroups are
+// dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2, and a
+// strip's 192-byte pixel rows share cache lines with the strips left and right
+// of it, so the linear id is remapped to keep neighbours on one XCD:
+//   map 0: raster (linear id = f * per_frame + strip);
+//   map 1: XCD x owns a contiguous run of (frame, strip) ids;
+//   map 2: XCD x owns the same band of strips in every frame.
+// The grid is 1-D with tail_grid() workgroups; false = nothing to do.
+struct TailUnit { int f, ty, gx; };
+__device__ __forceinline__ bool tail_unit(const Geom &g, int n_frames, int map, TailUnit &u) {
+    const int groups_x = (g.W + 63) >> 6, per_frame = groups_x * (g.H >> 3);
+    const long long total = (long long)per_frame * n_frames;
+    const long long L = blockIdx.x;
+    long long id;
+    if (map == 1) {
+        const long long chunk = (total + 7) >> 3;
+        id = (L & 7) * chunk + (L >> 3);
+        if ((L >> 3) >= chunk || id >= total) return false;
+    } else if (map == 2) {
+        const int cs = (per_frame + 7) >> 3;
+        const long long i = L >> 3;
+        const int s = (int)(L & 7) * cs + (int)(i % cs);
+        if (s >= per_frame || i / cs >= n_frames) return false;
+        id = (i / cs) * per_frame + s;
+    } else {
+        id = L;
+        if (id >= total) return false;
+    }
+    u.f = (int)(id / per_frame);
+    const int s = (int)(id - (long long)u.f * per_frame);
+    u.ty = s / groups_x;
+    u.gx = s - u.ty * groups_x;
+    return true;
+}
+inline unsigned tail_grid(const Geom &g, int n_frames, int map) {
+    const long long per_frame = (long long)((g.W + 63) >> 6) * (g.H >> 3);
+    if (map == 1) return (unsigned)(8 * ((per_frame * n_frames + 7) >> 3));
+    if (map == 2) return (unsigned)(8 * ((per_frame + 7) >> 3) * n_frames);
+    return (unsigned)(per_frame * n_frames);
+}
+
+// The coefficient planes (k_fdct) and the decoded frames (k_idct) are written once and
+// never read back by the kernel that writes them: non-temporal stores keep them from
+// displacing the reference frame and the pixel rows in L2 (k_fdct 0.49 -> 0.42 ms at
+// 29 x 1080p).  Non-temporal *loads* of the pixel rows were measured too and lose
+// (0.52 ms): neighbouring lanes' unaligned dword loads share cache lines.
+#define VCS_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+template <class T> struct Vec2 { typedef T type __attribute__((ext_vector_type(2))); };
+
 // --------------------------------------------------------------------------
 // k_fdct: MODE 0 = DCTCompressor.compress on a BGR image (DCTcompressor.py:
 //         49-74); MODE 1 = the encoder tail for a P frame: motion
 //         compensation + wrap-around residual + compress, fused
-//         (encoder.py:58-66).  grid = (tile groups per frame, frames).
+//         (encoder.py:58-66).  grid = tail_grid() strips.
 // DQ: D[64], Q[3][64], then 1/Q[3][64] (correctly rounded), float64, in HBM.
 // --------------------------------------------------------------------------
 template <int MODE, int CM, bool FASTDIV>
 __global__ __launch_bounds__(64) void k_fdct(
     const uint8_t *__restrict__ imgs, size_t img_stride, const uint8_t *__restrict__ ref,
     const int16_t *__restrict__ mvs, Geom g, const double *__restrict__ DQ,
-    typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride) {
+    typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride, int n_frames, int map) {
     __shared__ double s_t[8 * kTilePad];
     __shared__ typename CoeffT<CM>::type s_o[64 * kOutPad];  // [tile][row][col], padded rows
-    __shared__ double s_q[48 * kOutPad];  // Q[3][8][8] then 1/Q, rows padded to 9
+    __shared__ double s_q[(FASTDIV ? 48 : 24) * kOutPad];  // Q[3][8][8] (then 1/Q), rows padded to 9
     const int lane = threadIdx.x;
     const int t = lane >> 3, j = lane & 7;
-    const int groups_x = (g.W + 63) >> 6;
-    const int ty = blockIdx.x / groups_x, gx = blockIdx.x - ty * groups_x;
-    const int f = blockIdx.y;
+    TailUnit tu;
+    if (!tail_unit(g, n_frames, map, tu)) return;
+    const int ty = tu.ty, gx = tu.gx, f = tu.f;
     const int x = gx * 64 + lane;  // stage-1 pixel column of this lane
     const uint8_t *__restrict__ img = imgs + (size_t)f * img_stride;
     const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
@@ -171,8 +220,9 @@ __global__ __launch_bounds__(64) void k_fdct(
                 const OutT v0 = s_o[(tt * 8 + row) * kOutPad + jj];
                 const OutT v1 = s_o[(tt * 8 + row) * kOutPad + jj + 1];
                 OutT *o = out + ch * plane + (size_t)(ty * 8 + row) * g.W + xc;
-                struct alignas(2 * sizeof(OutT)) Pair { OutT a, b; };
-                *(Pair *)o = Pair{v0, v1};
+                typename Vec2<OutT>::type pr;
+                pr.x = v0, pr.y = v1;
+                VCS_NT_STORE(pr, (typename Vec2<OutT>::type *)o);
             }
         }
     }
@@ -186,14 +236,15 @@ template <int MODE, int CM>
 __global__ __launch_bounds__(64) void k_idct(
     const typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride,
     const uint8_t *__restrict__ ref, const int16_t *__restrict__ mvs, Geom g,
-    const double *__restrict__ DQ, uint8_t *__restrict__ outs, size_t out_stride) {
+    const double *__restrict__ DQ, uint8_t *__restrict__ outs, size_t out_stride, int n_frames,
+    int map) {
     __shared__ double s_t[8 * kTilePad];
     __shared__ double s_q[24 * kOutPad];  // Q[3][8][8], rows padded to 9
     const int lane = threadIdx.x;
     const int t = lane >> 3, j = lane & 7;
-    const int groups_x = (g.W + 63) >> 6;
-    const int ty = blockIdx.x / groups_x, gx = blockIdx.x - ty * groups_x;
-    const int f = blockIdx.y;
+    TailUnit tu;
+    if (!tail_unit(g, n_frames, map, tu)) return;
+    const int ty = tu.ty, gx = tu.gx, f = tu.f;
     const int x = gx * 64 + lane;
     const int xl = min(x, g.W - 1);  // lanes past the frame edge: clamped loads, no stores
     const size_t plane = (size_t)g.H * g.W;
@@ -257,13 +308,14 @@ __global__ __launch_bounds__(64) void k_idct(
         b[3 * jj + 1] = (uint8_t)(G + (int)((p >> 8) & 255));
         b[3 * jj + 2] = (uint8_t)(R + (int)((p >> 16) & 255));
     }
-    uint2 *o = (uint2 *)(outs + (size_t)f * out_stride + (size_t)y * g.pitch + (size_t)(3 * xo));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 *o = (u32x2 *)(outs + (size_t)f * out_stride + (size_t)y * g.pitch + (size_t)(3 * xo));
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-        uint2 v;
+        u32x2 v;
         v.x = b[8 * q] | (b[8 * q + 1] << 8) | (b[8 * q + 2] << 16) | ((uint32_t)b[8 * q + 3] << 24);
         v.y = b[8 * q + 4] | (b[8 * q + 5] << 8) | (b[8 * q + 6] << 16) | ((uint32_t)b[8 * q + 7] << 24);
-        o[q] = v;
+        VCS_NT_STORE(v, o + q);
     }
 }
 

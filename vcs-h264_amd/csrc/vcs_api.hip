@@ -232,18 +232,29 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     return t_end(c, &ev);
 }
 
+// strip -> workgroup mapping of k_fdct / k_idct (dct_kernels.hpp, tail_unit)
+static int tail_map() {
+    static const int m = [] {
+        const char *e = getenv("VCS_TAIL_MAP");
+        const int v = e ? atoi(e) : 0;
+        return v < 0 || v > 2 ? 0 : v;
+    }();
+    return m;
+}
+
 template <int MODE>
 int launch_fdct(vcs_ctx *c, int tslot, const uint8_t *imgs, size_t stride, const uint8_t *ref,
                 const int16_t *mv, int n, void *planes, size_t pstride_elems) {
     if (n == 0) return VCS_OK;
     const Geom &g = c->g;
-    dim3 grid(((g.W + 63) / 64) * (g.H / 8), n), block(64);
+    const int map = tail_map();
+    dim3 grid(tail_grid(g, n, map)), block(64);
     EvPair ev;
     int rc = t_begin(c, tslot, &ev);
     if (rc) return rc;
 #define VCS_FDCT(CM, FD, T)                                                                  \
     hipLaunchKernelGGL((k_fdct<MODE, CM, FD>), grid, block, 0, c->stream, imgs, stride, ref, mv, \
-                       g, c->d_DQ, (T *)planes, pstride_elems)
+                       g, c->d_DQ, (T *)planes, pstride_elems, n, map)
     switch (c->coeff_mode) {
         case VCS_COEFF_F64:
             if (c->fastdiv) VCS_FDCT(0, true, double); else VCS_FDCT(0, false, double);
@@ -264,23 +275,24 @@ int launch_idct(vcs_ctx *c, int tslot, const void *planes, size_t pstride_elems,
                 const uint8_t *ref, const int16_t *mv, int n, uint8_t *outs, size_t ostride) {
     if (n == 0) return VCS_OK;
     const Geom &g = c->g;
-    dim3 grid(((g.W + 63) / 64) * (g.H / 8), n), block(64);
+    const int map = tail_map();
+    dim3 grid(tail_grid(g, n, map)), block(64);
     EvPair ev;
     int rc = t_begin(c, tslot, &ev);
     if (rc) return rc;
     switch (c->coeff_mode) {
         case VCS_COEFF_F64:
             hipLaunchKernelGGL((k_idct<MODE, 0>), grid, block, 0, c->stream, (const double *)planes,
-                               pstride_elems, ref, mv, g, c->d_DQ, outs, ostride);
+                               pstride_elems, ref, mv, g, c->d_DQ, outs, ostride, n, map);
             break;
         case VCS_COEFF_F32:
             hipLaunchKernelGGL((k_idct<MODE, 1>), grid, block, 0, c->stream, (const float *)planes,
-                               pstride_elems, ref, mv, g, c->d_DQ, outs, ostride);
+                               pstride_elems, ref, mv, g, c->d_DQ, outs, ostride, n, map);
             break;
         default:
             hipLaunchKernelGGL((k_idct<MODE, 2>), grid, block, 0, c->stream,
                                (const int16_t *)planes, pstride_elems, ref, mv, g, c->d_DQ, outs,
-                               ostride);
+                               ostride, n, map);
             break;
     }
     return t_end(c, &ev);
