@@ -11,8 +11,8 @@
 //
 // Mapping: one wavefront owns 8 horizontally adjacent tiles (64 px x 8 rows).
 // Stage 1, lane = (tile t, column j): the lane holds column j of its tile for
-// the three channels in registers and multiplies by the wave-uniform DCT
-// matrix (scalar loads).  The 8x8 intermediate goes through LDS once to turn
+// the three channels in registers and multiplies by the DCT matrix (compile-
+// time constants, kDct8).  The 8x8 intermediate goes through LDS once to turn
 // columns into rows; stage 2, lane = (tile t, row i), produces 8 horizontally
 // adjacent outputs per lane, i.e. 64 contiguous bytes of a float64 plane.
 #pragma once
@@ -35,6 +35,33 @@ __device__ __forceinline__ typename CoeffT<CM>::type coeff_pack(double v) {
     else if constexpr (CM == 1) return (float)v;
     else return (int16_t)(int)__builtin_rint(v);  // np.round: half to even
 }
+
+// The 8x8 DCT-II matrix of DCTcompressor.py:124-133, D[i][j] = sqrt(2/8) cos((2j+1) i pi/16)
+// (row 0: 1/sqrt(8)), as float64 bit patterns: the values the reference's NumPy expression
+// yields (tests/golden/dct_small.npz "dctmat"; also what libm's cos gives, oracle/vcs_oracle.c
+// vcso_dct_matrix).  Not symmetric to the last bit (36 distinct magnitudes), so it is kept as
+// 64 literals.  Compile-time constants on purpose: as a runtime table the 128 SGPRs it needs
+// do not fit the scalar register file and hipcc spilled them through VGPR lanes -- a third of
+// k_fdct's and half of k_idct's vector instructions were v_readlane / v_writelane.
+#define VCS_DCT8_TABLE \
+    0x1.6a09e667f3bccp-2, 0x1.6a09e667f3bccp-2, 0x1.6a09e667f3bccp-2, 0x1.6a09e667f3bccp-2, \
+    0x1.6a09e667f3bccp-2, 0x1.6a09e667f3bccp-2, 0x1.6a09e667f3bccp-2, 0x1.6a09e667f3bccp-2, \
+    0x1.f6297cff75cb0p-2, 0x1.a9b66290ea1a3p-2, 0x1.1c73b39ae68c9p-2, 0x1.8f8b83c69a60dp-4, \
+    -0x1.8f8b83c69a608p-4, -0x1.1c73b39ae68c6p-2, -0x1.a9b66290ea1a4p-2, -0x1.f6297cff75cb0p-2, \
+    0x1.d906bcf328d46p-2, 0x1.87de2a6aea964p-3, -0x1.87de2a6aea962p-3, -0x1.d906bcf328d46p-2, \
+    -0x1.d906bcf328d47p-2, -0x1.87de2a6aea96dp-3, 0x1.87de2a6aea967p-3, 0x1.d906bcf328d44p-2, \
+    0x1.a9b66290ea1a3p-2, -0x1.8f8b83c69a608p-4, -0x1.f6297cff75cb0p-2, -0x1.1c73b39ae68c8p-2, \
+    0x1.1c73b39ae68c5p-2, 0x1.f6297cff75cb0p-2, 0x1.8f8b83c69a61dp-4, -0x1.a9b66290ea1a2p-2, \
+    0x1.6a09e667f3bcdp-2, -0x1.6a09e667f3bccp-2, -0x1.6a09e667f3bcep-2, 0x1.6a09e667f3bcbp-2, \
+    0x1.6a09e667f3bcep-2, -0x1.6a09e667f3bc5p-2, -0x1.6a09e667f3bc9p-2, 0x1.6a09e667f3bc4p-2, \
+    0x1.1c73b39ae68c9p-2, -0x1.f6297cff75cb0p-2, 0x1.8f8b83c69a60cp-4, 0x1.a9b66290ea1a5p-2, \
+    -0x1.a9b66290ea1a2p-2, -0x1.8f8b83c69a602p-4, 0x1.f6297cff75cb2p-2, -0x1.1c73b39ae68c2p-2, \
+    0x1.87de2a6aea964p-3, -0x1.d906bcf328d47p-2, 0x1.d906bcf328d44p-2, -0x1.87de2a6aea965p-3, \
+    -0x1.87de2a6aea971p-3, 0x1.d906bcf328d46p-2, -0x1.d906bcf328d43p-2, 0x1.87de2a6aea95fp-3, \
+    0x1.8f8b83c69a60dp-4, -0x1.1c73b39ae68c8p-2, 0x1.a9b66290ea1a5p-2, -0x1.f6297cff75cb2p-2, \
+    0x1.f6297cff75cb0p-2, -0x1.a9b66290ea1a1p-2, 0x1.1c73b39ae68c2p-2, -0x1.8f8b83c69a616p-4
+__device__ const double kDct8[64] = {VCS_DCT8_TABLE};
+static const double kDct8Host[64] = {VCS_DCT8_TABLE};
 
 // One BGR pixel as the low 3 bytes of an unaligned dword load (the buffers carry
 // slack behind the last pixel): one load per pixel instead of three.
@@ -128,7 +155,7 @@ template <class T> struct Vec2 { typedef T type __attribute__((ext_vector_type(2
 //         49-74); MODE 1 = the encoder tail for a P frame: motion
 //         compensation + wrap-around residual + compress, fused
 //         (encoder.py:58-66).  grid = tail_grid() strips.
-// DQ: D[64], Q[3][64], then 1/Q[3][64] (correctly rounded), float64, in HBM.
+// DQ: D[64] (unused here: kDct8), Q[3][64], then 1/Q[3][64] (correctly rounded), float64, in HBM.
 // --------------------------------------------------------------------------
 template <int MODE, int CM, bool FASTDIV>
 __global__ __launch_bounds__(64) void k_fdct(
@@ -146,7 +173,6 @@ __global__ __launch_bounds__(64) void k_fdct(
     const int x = gx * 64 + lane;  // stage-1 pixel column of this lane
     const uint8_t *__restrict__ img = imgs + (size_t)f * img_stride;
     const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
-    const double *__restrict__ D = DQ;
     const double *__restrict__ Q = DQ + 64;
 
     // ---- Q (and 1/Q) into LDS: later reads must not share vmcnt with the stores --
@@ -186,7 +212,7 @@ __global__ __launch_bounds__(64) void k_fdct(
         for (int i = 0; i < 8; i++) {
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) acc = __builtin_fma(D[i * 8 + k], X[ch][k], acc);
+            for (int k = 0; k < 8; k++) acc = __builtin_fma(kDct8[i * 8 + k], X[ch][k], acc);
             s_t[t * kTilePad + i * 8 + j] = acc;
         }
         wave_lds_fence();
@@ -201,7 +227,7 @@ __global__ __launch_bounds__(64) void k_fdct(
             for (int jj = 0; jj < 8; jj++) {
                 double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) acc = __builtin_fma(T[k], D[jj * 8 + k], acc);
+                for (int k = 0; k < 8; k++) acc = __builtin_fma(T[k], kDct8[jj * 8 + k], acc);
                 // :71 np.true_divide; parked for the row-contiguous store below
                 s_o[(t * 8 + j) * kOutPad + jj] = coeff_pack<CM>(
                     FASTDIV ? div_markstein(acc, q[jj], rq[jj]) : acc / q[jj]);
@@ -250,7 +276,6 @@ __global__ __launch_bounds__(64) void k_idct(
     const size_t plane = (size_t)g.H * g.W;
     const typename CoeffT<CM>::type *__restrict__ in = planes + (size_t)f * planes_stride;
     const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
-    const double *__restrict__ D = DQ;
     const double *__restrict__ Q = DQ + 64;
 
     // ---- every global load up front, branch-free ----------------------------------
@@ -279,7 +304,7 @@ __global__ __launch_bounds__(64) void k_idct(
         for (int i = 0; i < 8; i++) {
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) acc = __builtin_fma(D[k * 8 + i], X[ch][k], acc);
+            for (int k = 0; k < 8; k++) acc = __builtin_fma(kDct8[k * 8 + i], X[ch][k], acc);
             s_t[t * kTilePad + i * 8 + j] = acc;
         }
         wave_lds_fence();
@@ -292,7 +317,7 @@ __global__ __launch_bounds__(64) void k_idct(
         for (int jj = 0; jj < 8; jj++) {
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) acc = __builtin_fma(T[k], D[k * 8 + jj], acc);
+            for (int k = 0; k < 8; k++) acc = __builtin_fma(T[k], kDct8[k * 8 + jj], acc);
             ycc[ch][jj] = ((int)acc + 128) & 255;
         }
     }
