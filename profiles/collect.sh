@@ -5,6 +5,8 @@
 #   1. --kernel-trace --stats of the default bench command (per-kernel time)
 #   2. PMC passes, each in its own run (FETCH_SIZE and WRITE_SIZE cannot share a
 #      pass; never combined with sys/hip/hsa tracing)
+# Afterwards, here: cp gpurun_out/profiles_<tag>/{pmc_per_dispatch.json,kernel_stats.csv} profiles/<tag>/
+# and python profiles/make_traffic.py profiles/<tag>/pmc_per_dispatch.json -> profiles/hbm_traffic.json
 tag=${1:-r01}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/profiles_$tag
