@@ -18,6 +18,8 @@
 namespace vcs {
 
 constexpr int kMe16NewN = 4;  // ceil(16 rows * 13 groups / 64 lanes)
+constexpr int kMe16CurPitch = 20;  // dwords per re-packed current row in LDS (me16r_slabs)
+constexpr int kMe16Pass2Max = 36;  // at most 100 - 64 candidates in the second pass
 
 struct Me16rRegs {
     uint32_t rv[3], cv[3];
@@ -73,7 +75,7 @@ __device__ __forceinline__ void me16r_rows(const uint8_t *s_win, const uint32_t 
     for (int k = 0; k < 16; k++) {
         const int cur = k & 1, nxt = cur ^ 1;
         if (k + 1 < 16) {
-            if (MODE == kMe16Search) me16_ld(c[nxt], s_cur + (k + 1) * 16);
+            if (MODE == kMe16Search) me16_ld(c[nxt], s_cur + (k + 1) * kMe16CurPitch);
             const int o0 = base0 + (k + 1) * ROWB - ((k + 1) >= wrap0 ? 64 * ROWB : 0);
             me16_ld(a[nxt], s_win + o0);
             if (TWO) {
@@ -93,15 +95,72 @@ __device__ __forceinline__ void me16r_rows(const uint8_t *s_win, const uint32_t 
     }
 }
 
+// ---- second pass as 2-row slabs ------------------------------------------------
+// A block has up to 100 candidates: 64 fill the first pass, and the n2 = ncand - 64
+// others (36 for an interior block) used to leave 28+ of the 64 lanes idle for 16
+// more rows.  Instead each of them is cut into eight 2-row slabs: 8 * n2 (candidate,
+// slab) items = ceil(n2 / 8) wave passes of 2 rows -- 10 row evaluations instead of
+// 16 for n2 = 36.  Item q = 64 * sp + lane -> slab q & 7 (the lane's slab never
+// changes), candidate 64 + (q >> 3).  Every item adds its #{r >= c} to its
+// candidate's LDS counter (ds_add_u32).  The re-packed current rows are kept at a
+// pitch of 20 dwords so that the eight slabs of a lane group read eight different
+// bank groups.  Row loads run one row ahead of the evaluation, as in me16r_rows.
+template <int ROWB>
+__device__ __forceinline__ void me16r_slabs(const uint8_t *s_win, const uint32_t *s_cur,
+                                            uint32_t *s_part, int B, int n2, int ncj, int lane) {
+    const int nsp = (n2 + 7) >> 3;                   // wave passes (uniform, 1..5)
+    const uint32_t inv = 65536u / (uint32_t)ncj + 1u;  // cand / ncj for cand < 128, ncj <= 10
+    const int slab = lane & 7, l3 = lane >> 3;
+    const uint32_t *cptr =
+        (const uint32_t *)__builtin_assume_aligned(s_cur + slab * 2 * kMe16CurPitch, 16);
+    Me16Q a[2], c[2];
+    int c2 = 0, o1 = 0;
+    // issues the loads of row (t & 1) of sub-pass t >> 1
+    auto ld = [&](int t, Me16Q &qa, Me16Q &qc) {
+        if ((t & 1) == 0) {
+            c2 = 8 * (t >> 1) + l3;
+            const int cand = 64 + c2;
+            const int ci = (int)(((uint32_t)cand * inv) >> 16), cj = cand - ci * ncj;
+            const int slot = (B + 5 * ci + 2 * slab) & 63;
+            const int o0 = slot * ROWB + cj * 16;
+            o1 = o0 + (slot == 63 ? -63 * ROWB : ROWB);
+            me16_ld(qc, cptr);
+            me16_ld(qa, s_win + o0);
+        } else {
+            me16_ld(qc, cptr + kMe16CurPitch);
+            me16_ld(qa, s_win + o1);
+        }
+    };
+    ld(0, a[0], c[0]);
+    uint32_t cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 2 * ((kMe16Pass2Max + 7) / 8); t++) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        if (t < 2 * nsp) {  // uniform
+            int c2_this = c2;  // ld(t + 1) of an even t + 1 moves c2 on to the next sub-pass
+            if (t + 1 < 2 * nsp) ld(t + 1, a[nxt], c[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            me16_keep4(c[cur]);  // per-lane addresses: keep the 4th read a ds_read_b128 too
+            me16_count13(a[cur], c[cur], cnt);
+            if (t & 1) {
+                if (c2_this < n2) atomicAdd(&s_part[c2_this], cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+                cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+            }
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64, 2) void k_me16r(
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
     Geom g, int n_frames, int seg_len, uint32_t *__restrict__ sums, int16_t *__restrict__ mv,
     uint32_t *__restrict__ n_static, unsigned long long *__restrict__ cost_out) {
     constexpr int ROWB = 18 * 16;
-    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe16Rows * ROWB + 16 * 64];
+    __shared__ __attribute__((aligned(16)))
+    uint8_t s_lds[kMe16Rows * ROWB + 16 * 4 * kMe16CurPitch + 4 * kMe16Pass2Max];
     uint8_t *const s_win = s_lds;
     uint32_t *const s_cur = (uint32_t *)(s_lds + kMe16Rows * ROWB);
+    uint32_t *const s_part = s_cur + 16 * kMe16CurPitch;  // second-pass counters (me16r_slabs)
     constexpr int BS = 16, WIN = 32, STEP = 5;
     const int lane = threadIdx.x;
 
@@ -210,8 +269,9 @@ __global__ __launch_bounds__(64, 2) void k_me16r(
                 for (int q = 0; q < 4; q++) {
                     const int e = lane + 64 * q, row = e / 13, j = e - row * 13;
                     const uint32_t padm = ((j & 3) == 3 || j == 12) ? 0xFF000000u : 0u;
-                    if (e < 16 * 13) s_cur[row * 16 + j] = ~A.cq[q] | padm;
+                    if (e < 16 * 13) s_cur[row * kMe16CurPitch + j] = ~A.cq[q] | padm;
                 }
+                if (lane < kMe16Pass2Max) s_part[lane] = 0;
             }
             wave_lds_fence();
 
@@ -230,10 +290,16 @@ __global__ __launch_bounds__(64, 2) void k_me16r(
             const int base0 = s0 * ROWB + cj0 * 16, base1 = s1 * ROWB + cj1 * 16;
 
             uint32_t acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
-            if (ncand > 64)
-                me16r_rows<MODE, true, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
-            else
+            if (MODE == kMe16Search && ncand > 64) {
                 me16r_rows<MODE, false, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
+                me16r_slabs<ROWB>(s_win, s_cur, s_part, B, ncand - 64, ncj, lane);
+                wave_lds_fence();
+                acc1[0] = s_part[min(lane, kMe16Pass2Max - 1)];
+            } else if (ncand > 64) {
+                me16r_rows<MODE, true, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
+            } else {
+                me16r_rows<MODE, false, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
+            }
 
             if (MODE == kMe16Sums) {
                 uint32_t *__restrict__ sb = sums + (size_t)(by * g.nbx + bxi) * kMe16SumStride;
