@@ -105,10 +105,12 @@ __device__ __forceinline__ void me16r_rows(const uint8_t *s_win, const uint32_t 
 // candidate's LDS counter (ds_add_u32).  The re-packed current rows are kept at a
 // pitch of 20 dwords so that the eight slabs of a lane group read eight different
 // bank groups.  Row loads run one row ahead of the evaluation, as in me16r_rows.
-template <int ROWB>
+// NSP: wave passes when known at compile time (5 = interior block: straight-line code, so
+// that hipcc keeps counted lgkmcnt waits and the one-row-ahead pipelining), 0 = ceil(n2 / 8).
+template <int ROWB, int NSP>
 __device__ __forceinline__ void me16r_slabs(const uint8_t *s_win, const uint32_t *s_cur,
                                             uint32_t *s_part, int B, int n2, int ncj, int lane) {
-    const int nsp = (n2 + 7) >> 3;                   // wave passes (uniform, 1..5)
+    const int nsp = NSP ? NSP : (n2 + 7) >> 3;       // wave passes (uniform, 1..5)
     const uint32_t inv = 65536u / (uint32_t)ncj + 1u;  // cand / ncj for cand < 128, ncj <= 10
     const int slab = lane & 7, l3 = lane >> 3;
     const uint32_t *cptr =
@@ -134,9 +136,9 @@ __device__ __forceinline__ void me16r_slabs(const uint8_t *s_win, const uint32_t
     ld(0, a[0], c[0]);
     uint32_t cnt[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 2 * ((kMe16Pass2Max + 7) / 8); t++) {
+    for (int t = 0; t < 2 * (NSP ? NSP : (kMe16Pass2Max + 7) / 8); t++) {
         const int cur = t & 1, nxt = cur ^ 1;
-        if (t < 2 * nsp) {  // uniform
+        if (NSP || t < 2 * nsp) {  // uniform
             int c2_this = c2;  // ld(t + 1) of an even t + 1 moves c2 on to the next sub-pass
             if (t + 1 < 2 * nsp) ld(t + 1, a[nxt], c[nxt]);
             __builtin_amdgcn_sched_barrier(0);
@@ -292,7 +294,10 @@ __global__ __launch_bounds__(64, 2) void k_me16r(
             uint32_t acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
             if (MODE == kMe16Search && ncand > 64) {
                 me16r_rows<MODE, false, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
-                me16r_slabs<ROWB>(s_win, s_cur, s_part, B, ncand - 64, ncj, lane);
+                if (ncand == 100)
+                    me16r_slabs<ROWB, 5>(s_win, s_cur, s_part, B, 36, ncj, lane);
+                else
+                    me16r_slabs<ROWB, 0>(s_win, s_cur, s_part, B, ncand - 64, ncj, lane);
                 wave_lds_fence();
                 acc1[0] = s_part[min(lane, kMe16Pass2Max - 1)];
             } else if (ncand > 64) {
