@@ -259,6 +259,30 @@ def test_dct_extremes_vs_oracle(vh, oracle):
         assert np.array_equal(c.decompress(wild), oracle.decompress(wild))
 
 
+def test_planes_identical_to_the_bit(vh, oracle):
+    """float64 planes compared as raw 64-bit patterns: np.array_equal calls -0.0 and +0.0
+    equal, a stored bitstream would not.  Flat and half-flat frames produce exact zeros
+    (np.true_divide keeps the numerator's sign, DCTcompressor.py:71; the exact 3-FMA
+    division of k_fdct would turn a -0.0 numerator into +0.0, but fma chains that start
+    from +0.0 never produce one)."""
+    rng = np.random.default_rng(17)
+    H, W = 64, 128
+    flat = np.full((H, W, 3), 97, np.uint8)
+    half = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    half[:, W // 2:] = (200, 3, 77)
+    dark = np.zeros((H, W, 3), np.uint8)
+    dark[::2] = 255
+    n_zero = 0
+    with vh.Context(H, W, 8) as c:
+        for img in (flat, half, dark, rng.integers(0, 256, (H, W, 3), dtype=np.uint8)):
+            want = oracle.compress(img)
+            got = c.compress(img)
+            assert np.array_equal(got.view(np.int64), want.view(np.int64))
+            n_zero += int(np.count_nonzero(want == 0))
+            assert not np.any((want == 0) & np.signbit(want))
+    assert n_zero > 0  # exact zeros did occur
+
+
 def test_coeff_modes_vs_oracle(vh, oracle):
     from synth import synth_v1
     ref, cur = synth_v1(64, 96, seed=11)
@@ -525,8 +549,8 @@ def test_gop_1080p_rolling_kernel(vh, oracle):
 def test_forced_kernel_variants_subprocess():
     """The same parity cases with the rolling-window kernel forced on small and
     ragged frames (VCS_ME16_ROLL=2), with it disabled (=0), and with the generic
-    kernel forced (VCS_ME_GENERIC=1), and the DCT cases with the exact 3-FMA
-    division (VCS_FAST_DIV=1): one child process per setting."""
+    kernel forced (VCS_ME_GENERIC=1), and the DCT cases with the IEEE division
+    sequence instead of the exact 3-FMA one (VCS_FAST_DIV=0): one child process per setting."""
     import os
     import subprocess
     import sys
@@ -535,7 +559,7 @@ def test_forced_kernel_variants_subprocess():
            "4k_frame or empty_and_tiny or golden_real_small or gop_1080p_vs_oracle")
     dct = "golden_dct_small or encode_decode_vs_oracle or dct_extremes or coeff_modes"
     for env_add, k in (({"VCS_ME16_ROLL": "2"}, sel), ({"VCS_ME16_ROLL": "0"}, sel),
-                       ({"VCS_ME_GENERIC": "1"}, sel), ({"VCS_FAST_DIV": "1"}, dct)):
+                       ({"VCS_ME_GENERIC": "1"}, sel), ({"VCS_FAST_DIV": "0"}, dct)):
         env = dict(os.environ, **env_add)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
                             "-m", "gpu", "-x", "-q", "-k", k, "-p", "no:cacheprovider"],

@@ -72,11 +72,14 @@ __device__ __forceinline__ uint32_t load_px(const uint8_t *p) {
 }
 // a / b, correctly rounded, from y = RN(1 / b) in three fused operations
 // (Markstein): q = RN(a*y); r = RN(a - q*b) (exact); result = RN(q + r*y).
-// Valid when nothing over/underflows and b's significand is not all ones; the
-// host only selects this path for such Q tables (vcs_api.hip, q_fastdiv_ok).
+// Valid when nothing over/underflows, b > 0 and b's significand is not all ones; the
+// host only selects this path for such Q tables (vcs_api.hip, refresh_q).
 // Bit-identical to IEEE division: 1.5e9 random / adversarial cases checked
-// against a / b on the CPU for every integer Q in 1..255, 0 mismatches (a
-// zero quotient may differ in sign only).
+// against a / b on the CPU for every integer Q in 1..255, 0 mismatches.  The one
+// input where the three operations differ from a / b is a = -0.0 (+0.0 instead of
+// -0.0), and k_fdct never divides it: its numerators are k-ascending fma chains that
+// start from +0.0, and round-to-nearest sums are -0.0 only if every term is
+// (tests/test_gpu_parity.py compares the planes as raw 64-bit patterns).
 __device__ __forceinline__ double div_markstein(double a, double b, double y) {
     const double q = a * y;
     const double r = __builtin_fma(-q, b, a);
@@ -162,8 +165,14 @@ __global__ __launch_bounds__(64) void k_fdct(
     const uint8_t *__restrict__ imgs, size_t img_stride, const uint8_t *__restrict__ ref,
     const int16_t *__restrict__ mvs, Geom g, const double *__restrict__ DQ,
     typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride, int n_frames, int map) {
+    // s_t: stage-1 result, [tile][row][col]; s_o: the quantised strip parked for the
+    // row-contiguous store, [tile][row][col] with padded rows.  They share one buffer:
+    // every lane has its row of s_t in registers before the first s_o write (LDS
+    // operations of one wave execute in order).
+    static_assert(64 * kOutPad * sizeof(typename CoeffT<CM>::type) <= 8 * kTilePad * sizeof(double),
+                  "s_o must fit in s_t");
     __shared__ double s_t[8 * kTilePad];
-    __shared__ typename CoeffT<CM>::type s_o[64 * kOutPad];  // [tile][row][col], padded rows
+    typename CoeffT<CM>::type *const s_o = (typename CoeffT<CM>::type *)s_t;
     __shared__ double s_q[(FASTDIV ? 48 : 24) * kOutPad];  // Q[3][8][8] (then 1/Q), rows padded to 9
     const int lane = threadIdx.x;
     const int t = lane >> 3, j = lane & 7;
@@ -220,6 +229,7 @@ __global__ __launch_bounds__(64) void k_fdct(
         double T[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) T[k] = s_t[t * kTilePad + j * 8 + k];
+        wave_lds_fence();  // s_o overwrites s_t
         {
             const double *q = s_q + (ch * 8 + j) * kOutPad;
             const double *rq = q + 24 * kOutPad;  // correctly rounded 1 / Q
@@ -251,6 +261,7 @@ __global__ __launch_bounds__(64) void k_fdct(
                 VCS_NT_STORE(pr, (typename Vec2<OutT>::type *)o);
             }
         }
+        wave_lds_fence();  // the next channel's s_t overwrites s_o
     }
 }
 

@@ -139,7 +139,7 @@ int refresh_me_geometry(vcs_ctx *c) {
 }
 
 // Fills 1/Q behind Q and decides whether the 3-FMA division is exact for it:
-// every |Q| within [2^-60, 2^60] and no all-ones significand (Markstein).
+// every Q within [2^-60, 2^60] (positive) and no all-ones significand (Markstein).
 void refresh_q(vcs_ctx *c) {
     bool ok = true;
     for (int i = 0; i < 192; i++) {
@@ -147,15 +147,14 @@ void refresh_q(vcs_ctx *c) {
         c->hDQ[256 + i] = 1.0 / q;
         uint64_t bits;
         memcpy(&bits, &q, 8);
-        const double aq = fabs(q);
-        if (!(aq >= 0x1p-60 && aq <= 0x1p60) || (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull)
+        if (!(q >= 0x1p-60 && q <= 0x1p60) || (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull)
             ok = false;
     }
-    // Opt-in (VCS_FAST_DIV=1): measured on MI355X the fused tail kernel is bound by
-    // its float64 stores, and the extra 1/Q loads cost more than the IEEE division
-    // sequence saves (0.64 vs 0.60 ms per 29-frame GOP), so the default stays IEEE.
+    // Default when the table admits it; VCS_FAST_DIV=0 forces the IEEE division sequence
+    // (tests run both).  k_fdct is co-limited by vector issue once its stores are
+    // non-temporal: 4 operations per quotient instead of 11 + a quarter-rate v_rcp_f64.
     const char *e = getenv("VCS_FAST_DIV");
-    c->fastdiv = ok && e && e[0] == '1';
+    c->fastdiv = ok && !(e && e[0] == '0');
 }
 
 // ---- timing brackets -----------------------------------------------------
