@@ -212,7 +212,13 @@ def main():
             # the motion search is bound by vector-ALU issue, not by HBM: say how close it
             # is to THAT roof (wave-instructions per launch from profiles/r01 PMC, 16-lane
             # SIMDs issue one wave64 instruction per 4 cycles)
-            valu_per_mb = 1457.0
+            valu_per_mb = 1216.0
+            try:  # the committed PMC count for this workload, if present
+                kj = tj["kernels"]["k_me16r"]
+                valu_per_mb = round(kj["valu_wave_insts_per_dispatch"] /
+                                    (tj["workload"]["frames_per_launch"] * N), 1)
+            except Exception:
+                pass
             peak = 256 * 4 * 2.4e9 / 4
             me_ms = ms[vcs_hip.T_ME] / max(1, int(launches[vcs_hip.T_ME]))
             ach = valu_per_mb * n * N / (me_ms * 1e-3)

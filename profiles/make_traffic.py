@@ -18,7 +18,7 @@ ALG = {  # algorithmic bytes per launch (29 P frames)
     "k_fdct<residual>": FRAMES * (10 * F + 4 * N),
     "k_me16<sums>": F + N * 100 * 4,
 }
-PMC_NAMES = {"vcs::k_me16r<0>": "k_me16r", "vcs::k_fdct<1, 0, false>": "k_fdct<residual>",
+PMC_NAMES = {"vcs::k_me16r<0>": "k_me16r", "vcs::k_fdct<1, 0, true>": "k_fdct<residual>",
              "vcs::k_me16<18, 1>": "k_me16<sums>"}
 
 
