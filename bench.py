@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-decode", action="store_true",
                     help="also time the decode kernel over the GOP (reported next to the line)")
+    ap.add_argument("--serial-comm", action="store_true",
+                    help="multi-GPU: broadcast -> kernels -> all-gather strictly in sequence "
+                         "instead of overlapping the collectives with the neighbouring GOPs' kernels")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed (RCCL) code path even with one rank")
     args = ap.parse_args()
@@ -105,19 +108,69 @@ def main():
     ref, frames = synth_gop(H, W, n, seed=1234, first=1 + rank * n)
     ctx.gop_reserve(n, with_decode=args.with_decode)
     ctx.gop_upload(0, frames)
+    overlap = False
     if use_dist:
         ptr, nb = ctx.dev_ptr(0)
         t_ref = torch.as_tensor(_DevBytes(ptr, nb), device="cuda")
         ptr, nb = ctx.dev_ptr(1)
         t_mv = torch.as_tensor(_DevBytes(ptr, nb), device="cuda")
-        t_all = torch.empty(world * t_mv.numel(), dtype=torch.uint8, device="cuda")
         if rank == 0:
             ctx.set_ref(ref)        # the I frame enters HBM on rank 0 only
         ctx.ref_written()
+        ctx.sync()
+        overlap = not args.serial_comm
+        if overlap:
+            # Collectives on their own stream, kernels on the context's stream, ordered by
+            # events only: the I frame of GOP k+1 is broadcast (into a staging buffer) while
+            # GOP k is being encoded, and GOP k's motion vectors are gathered (from a staging
+            # copy) while GOP k+1 is being encoded.  Every rank enqueues the collectives in
+            # the same order: bcast(0), bcast(1), gather(0), bcast(2), gather(1), ...
+            xs = torch.cuda.ExternalStream(ctx.stream_handle(), device=torch.device("cuda", local_rank))
+            cs = torch.cuda.Stream()
+            ref_stage = [t_ref.clone(), t_ref.clone()]   # rank 0: the decoder's output; others: filled by bcast
+            mv_stage = [torch.empty_like(t_mv), torch.empty_like(t_mv)]
+            t_all = [torch.empty(world * t_mv.numel(), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            ev_b = [torch.cuda.Event(), torch.cuda.Event()]   # broadcast into ref_stage[i] done   (cs)
+            ev_r = [torch.cuda.Event(), torch.cuda.Event()]   # ref_stage[i] copied to the context (xs)
+            ev_c = [torch.cuda.Event(), torch.cuda.Event()]   # kernels + copy into mv_stage[i]    (xs)
+            ev_g = [torch.cuda.Event(), torch.cuda.Event()]   # gather out of mv_stage[i] done     (cs)
+            torch.cuda.synchronize()
+            state = {"k": 0}
+
+            def issue_bcast(k):
+                i = k & 1
+                with torch.cuda.stream(cs):
+                    cs.wait_event(ev_r[i])           # GOP k-2 has taken its frame out of the buffer
+                    dist.broadcast(ref_stage[i], src=0)
+                    ev_b[i].record(cs)
+
+            issue_bcast(0)
+        else:
+            t_all = torch.empty(world * t_mv.numel(), dtype=torch.uint8, device="cuda")
     else:
         ctx.set_ref(ref)
 
     def step():
+        if overlap:
+            k = state["k"]
+            i = k & 1
+            state["k"] = k + 1
+            issue_bcast(k + 1)                       # next GOP's I frame, behind this GOP's kernels
+            xs.wait_event(ev_b[i])                   # this GOP's I frame has arrived
+            xs.wait_event(ev_g[i])                   # GOP k-2's vectors have left mv_stage[i]
+            with torch.cuda.stream(xs):
+                t_ref.copy_(ref_stage[i], non_blocking=True)
+                ev_r[i].record(xs)
+            ctx.ref_written()
+            ctx.gop_encode(0, n)                     # ME kernel + fused tail kernel
+            with torch.cuda.stream(xs):
+                mv_stage[i].copy_(t_mv, non_blocking=True)
+                ev_c[i].record(xs)
+            with torch.cuda.stream(cs):
+                cs.wait_event(ev_c[i])
+                dist.all_gather_into_tensor(t_all[i], mv_stage[i])   # motion-vector collection
+                ev_g[i].record(cs)
+            return
         if use_dist:
             ts = torch.cuda.current_stream().cuda_stream
             dist.broadcast(t_ref, src=0)             # I frame over xGMI (after the previous
@@ -133,7 +186,7 @@ def main():
     def fence():
         ctx.sync()
         if use_dist:
-            torch.cuda.synchronize()
+            torch.cuda.synchronize()                 # all torch streams, the collectives' included
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -202,7 +255,11 @@ def main():
                                                                   round(bs / 3)),
                        "frames_per_step_per_gpu": n, "macroblocks_per_frame": N,
                        "searched_block_fraction": round(searched, 4),
-                       "parallelism": "P frames sharded over %d GPU(s)" % world},
+                       "parallelism": "P frames sharded over %d GPU(s)" % world,
+                       "collectives": ("none" if not use_dist else
+                                       "RCCL broadcast (I frame) + all-gather (vectors) per GOP, " +
+                                       ("overlapped with the neighbouring GOPs' kernels" if overlap
+                                        else "in sequence with the kernels"))},
             "kernel_ms_per_step": {"me": round(ms[vcs_hip.T_ME] / args.steps, 4),
                                    "enc_tail": round(ms[vcs_hip.T_ENC_TAIL] / args.steps, 4)},
             "roofline": roof(dom),

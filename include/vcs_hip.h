@@ -186,6 +186,11 @@ int vcs_intra_chroma8x8(vcs_ctx *ctx, const uint8_t *Cr, const uint8_t *Cb, doub
  * `foreign_stream` is a hipStream_t (NULL = the legacy default stream).        */
 int vcs_stream_wait(vcs_ctx *ctx, void *foreign_stream);
 int vcs_stream_signal(vcs_ctx *ctx, void *foreign_stream);
+/* The context's own hipStream_t, for callers that order against it with their own
+ * events or enqueue device-to-device copies on it (bench.py wraps it in a
+ * torch.cuda.ExternalStream to overlap RCCL collectives with the kernels).  The
+ * stream stays owned by the context and dies with it.                          */
+int vcs_stream_handle(vcs_ctx *ctx, void **stream);
 
 /* ---- measurement ------------------------------------------------------- */
 /* With timing on, every kernel launch is bracketed by HIP events on the

@@ -1014,6 +1014,14 @@ int vcs_stream_signal(vcs_ctx *c, void *foreign_stream) {
     return VCS_OK;
 }
 
+int vcs_stream_handle(vcs_ctx *c, void **stream) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!stream) return fail(c, VCS_E_ARG, "null pointer");
+    *stream = (void *)c->stream;
+    return VCS_OK;
+}
+
 // ---- measurement -----------------------------------------------------------
 int vcs_timing_enable(vcs_ctx *c, int on) {
     int rc = use(c);

@@ -65,6 +65,7 @@ SIGNATURES = {
     "vcs_intra_chroma8x8": (ctypes.c_int, [_c_ctx, _u8p, _u8p, _f64p, _f64p, _f64p, _f64p, _f64p]),
     "vcs_stream_wait": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_signal": (ctypes.c_int, [_c_ctx, _vp]),
+    "vcs_stream_handle": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_void_p)]),
     "vcs_timing_enable": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
     "vcs_timing_reset": (ctypes.c_int, [_c_ctx]),
     "vcs_timing": (ctypes.c_int, [_c_ctx, _f64p, _u64p, ctypes.c_int]),
@@ -412,6 +413,12 @@ class Context:
     def stream_signal(self, foreign_stream):
         """`foreign_stream` waits for our stream."""
         self._ck(self._lib.vcs_stream_signal(self._h, ctypes.c_void_p(int(foreign_stream) or None)))
+
+    def stream_handle(self):
+        """The context's hipStream_t as an int (e.g. for torch.cuda.ExternalStream)."""
+        p = ctypes.c_void_p()
+        self._ck(self._lib.vcs_stream_handle(self._h, ctypes.byref(p)))
+        return int(p.value or 0)
 
     # -- measurement --------------------------------------------------------
     def timing_enable(self, on=True):
