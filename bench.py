@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-decode", action="store_true",
                     help="also time the decode kernel over the GOP (reported next to the line)")
+    ap.add_argument("--same-ref", action="store_true",
+                    help="diagnostic: do not declare a new I frame per step (the per-reference sum "
+                         "table is then built once, outside the timed region)")
     ap.add_argument("--serial-comm", action="store_true",
                     help="multi-GPU: broadcast -> kernels -> all-gather strictly in sequence "
                          "instead of overlapping the collectives with the neighbouring GOPs' kernels")
@@ -177,7 +180,8 @@ def main():
             ctx.stream_wait(ts)                      # step's all-gather; our stream waits for it)
         # every step is a new GOP: the per-reference work (k_me16's sum table) is
         # redone inside the timed region, once per GOP as in a real encode
-        ctx.ref_written()
+        if not args.same_ref:
+            ctx.ref_written()
         ctx.gop_encode(0, n)                         # ME kernel + fused tail kernel
         if use_dist:
             ctx.stream_signal(ts)                    # collectives wait for the kernels, GPU-side

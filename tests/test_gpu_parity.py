@@ -174,6 +174,35 @@ def test_golden_real_small(vh, nm):
                 assert np.array_equal(c.decode_p(mv, planes), g[nm + "_full16"])
 
 
+def _psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+@pytest.mark.parametrize("nm", ["jump", "corgi"])
+def test_psnr_matches_reference(vh, nm):
+    """BASELINE north_star: reconstruction within 1e-4 dB PSNR of the reference.  The
+    decoded frames are bit-identical (tests above), so the float64-plane path differs by
+    exactly 0.  The reduced-precision plane formats are NOT in the reference and are not
+    parity cases: its decoder truncates float64 to uint8 with wrap-around
+    (DCTcompressor.py:88), so a last-bit change of a coefficient can flip a pixel by 1 or
+    by 255 -- float32 planes land within a dB (either side), integer levels are a
+    different operating point altogether.  Both are only sanity-bounded here."""
+    g = load_golden("real_small.npz")
+    ref, cur = g[nm + "_ref"], g[nm + "_cur"]
+    want = _psnr(g[nm + "_full16"], cur)          # what the reference's decoder achieves
+    with ctx_for(vh, ref, 16) as c:
+        c.set_ref(ref)
+        mv, planes, _, _ = c.encode_p(cur)
+        assert abs(_psnr(c.decode_p(mv, planes), cur) - want) <= 1e-4
+        c.set_params(coeff_mode=vh.VCS_COEFF_F32)
+        mv, p32, _, _ = c.encode_p(cur)
+        assert abs(_psnr(c.decode_p(mv, p32), cur) - want) < 2.0
+        c.set_params(coeff_mode=vh.VCS_COEFF_I16)
+        mv, p16, _, _ = c.encode_p(cur)
+        assert _psnr(c.decode_p(mv, p16), cur) > 4.0
+
+
 # ---------------------------------------------------------------- oracle ----
 @pytest.mark.parametrize("H,W,bs", [
     (64, 64, 16), (72, 88, 8), (50, 70, 8), (70, 90, 16), (30, 26, 4), (33, 47, 5),

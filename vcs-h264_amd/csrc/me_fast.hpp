@@ -49,7 +49,6 @@ namespace vcs {
 constexpr int kMe16Rows = 64;        // 2 * win
 constexpr int kMe16Groups = 13;      // ceil(64 px / 5)
 constexpr int kMe16SumStride = 128;  // uint32 per block in the sum(r) table (100 used)
-enum { kMe16Search = 0, kMe16Sums = 1 };
 
 __device__ __forceinline__ uint4 load16_any_align(const uint8_t *p) {
     uint4 v;
@@ -98,46 +97,31 @@ __device__ __forceinline__ void me16_count13(const Me16Q &a, const Me16Q &c, uin
         asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[d & 3]) : "v"(t[d]));
     __builtin_amdgcn_sched_barrier(0);
 }
-// Byte sum of the 13 dwords (the 13th holds 3 data bytes + one foreign byte).
-__device__ __forceinline__ void me16_sum13(const Me16Q &a, uint32_t (&sum)[4]) {
-    me16_keep4(a);
-    const uint32_t r[13] = {a.q0.x, a.q0.y, a.q0.z, a.q0.w, a.q1.x, a.q1.y, a.q1.z,
-                            a.q1.w, a.q2.x, a.q2.y, a.q2.z, a.q2.w, a.q3.x & 0x00FFFFFFu};
-#pragma unroll
-    for (int d = 0; d < 13; d++) sum[d & 3] = __builtin_amdgcn_sad_u8(r[d], 0u, sum[d & 3]);
-}
-
 // All 16 rows of two candidates per lane (p0: candidate `lane`, p1: candidate
 // `lane + 64`) against the same re-packed current rows, fully unrolled and
 // software-pipelined one row ahead: the LDS reads of row k+1 are issued before
 // row k is evaluated (two waves per SIMD do not cover the LDS latency on their
 // own).  Scheduling fences keep hipcc from hoisting more than that one row
-// (which spills).  MODE kSums: byte sums instead of counts.
-template <int MODE, bool TWO, int ROWB>
+// (which spills).
+template <bool TWO, int ROWB>
 __device__ __forceinline__ void me16_rows(const uint32_t *s_cur, const uint8_t *p0,
                                           const uint8_t *p1, uint32_t (&acc0)[4],
                                           uint32_t (&acc1)[4]) {
     Me16Q c[2], a[2], b[2];
-    if (MODE == kMe16Search) me16_ld(c[0], s_cur);
+    me16_ld(c[0], s_cur);
     me16_ld(a[0], p0);
     if (TWO) me16_ld(b[0], p1);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const int cur = k & 1, nxt = cur ^ 1;
         if (k + 1 < 16) {
-            if (MODE == kMe16Search) me16_ld(c[nxt], s_cur + (k + 1) * 16);
+            me16_ld(c[nxt], s_cur + (k + 1) * 16);
             me16_ld(a[nxt], p0 + (k + 1) * ROWB);
             if (TWO) me16_ld(b[nxt], p1 + (k + 1) * ROWB);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (MODE == kMe16Search) {
-            me16_count13(a[cur], c[cur], acc0);
-            if (TWO) me16_count13(b[cur], c[cur], acc1);
-        } else {
-            me16_sum13(a[cur], acc0);
-            if (TWO) me16_sum13(b[cur], acc1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        me16_count13(a[cur], c[cur], acc0);
+        if (TWO) me16_count13(b[cur], c[cur], acc1);
     }
 }
 
@@ -199,7 +183,6 @@ __device__ __forceinline__ void me16_offsets(const Geom &g, int lane, Me16Offs &
 // the window is always fetched 64 rows deep; for blocks near the bottom edge
 // the extra rows lie in the slack behind the reference frame (the context
 // allocates it) and are never used.
-template <int MODE>
 __device__ __forceinline__ void me16_issue(const uint8_t *__restrict__ ref,
                                            const uint8_t *__restrict__ curs, size_t cur_stride,
                                            const uint32_t *__restrict__ sums, const Geom &g, int w,
@@ -211,33 +194,31 @@ __device__ __forceinline__ void me16_issue(const uint8_t *__restrict__ ref,
     const size_t blk_off = (size_t)y * g.pitch + (size_t)(48 * bxi);
     const int i_min = max(y - WIN, 0), j_min = max(x - WIN, 0);
     const uint8_t *__restrict__ wsrc = ref + (size_t)i_min * g.pitch + (size_t)(3 * j_min);
-    if (MODE == kMe16Search) {
-        const uint8_t *__restrict__ cblk = curs + (size_t)f * cur_stride + blk_off;  // uniform
-        const uint8_t *__restrict__ rblk = ref + blk_off;                             // uniform
+    const uint8_t *__restrict__ cblk = curs + (size_t)f * cur_stride + blk_off;  // uniform
+    const uint8_t *__restrict__ rblk = ref + blk_off;                             // uniform
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            R.rv[t] = *(const uint32_t *)(rblk + O.blk[t]);
-            R.cv[t] = *(const uint32_t *)(cblk + O.blk[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            uint32_t v;
-            __builtin_memcpy(&v, cblk + O.cq[t], 4);
-            R.cq[t] = v;
-        }
-        const uint32_t *__restrict__ sb = sums + (size_t)blk * kMe16SumStride;  // uniform
-        R.sr[0] = sb[lane];
-        R.sr[1] = sb[lane + 64];
+    for (int t = 0; t < 3; t++) {
+        R.rv[t] = *(const uint32_t *)(rblk + O.blk[t]);
+        R.cv[t] = *(const uint32_t *)(cblk + O.blk[t]);
     }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        uint32_t v;
+        __builtin_memcpy(&v, cblk + O.cq[t], 4);
+        R.cq[t] = v;
+    }
+    const uint32_t *__restrict__ sb = sums + (size_t)blk * kMe16SumStride;  // uniform
+    R.sr[0] = sb[lane];
+    R.sr[1] = sb[lane + 64];
 #pragma unroll
     for (int t = 0; t < kMe16Groups; t++) R.stg[t] = load16_any_align(wsrc + O.stg[t]);
 }
 
-// MODE kMe16Search: motion search of `total` work items (frame-major blocks).
-// MODE kMe16Sums:   fills sums[blk * 128 + cand] for the N blocks of `ref`.
+// Motion search of `total` work items (frame-major blocks); sums = the reference's
+// sum(r) table (k_me16_sums).
 // SLOTS: 16-byte slots per LDS window row; 18 is the conflict-free pitch (13 and 14 were
 // measured: more waves per CU, but their 2-way bank conflicts cost more than that gains).
-template <int SLOTS, int MODE>
+template <int SLOTS>
 __global__ __launch_bounds__(64, 2) void k_me16(
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
     Geom g, int total, uint32_t *__restrict__ sums, int16_t *__restrict__ mv,
@@ -261,7 +242,7 @@ __global__ __launch_bounds__(64, 2) void k_me16(
     Me16Offs O;
     me16_offsets(g, lane, O);
     Me16Regs A;
-    me16_issue<MODE>(ref, curs, cur_stride, sums, g, w, lane, O, A);
+    me16_issue(ref, curs, cur_stride, sums, g, w, lane, O, A);
 #ifdef VCS_ME16_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
@@ -271,7 +252,7 @@ __global__ __launch_bounds__(64, 2) void k_me16(
         // ---- prefetch the next block of this wave while this one is searched ------
         const int wn = w + nw;
         Me16Regs B;
-        me16_issue<MODE>(ref, curs, cur_stride, sums, g, min(wn, w_end - 1), lane, O, B);
+        me16_issue(ref, curs, cur_stride, sums, g, min(wn, w_end - 1), lane, O, B);
         ME16_STAMP(0);  // issue of the next block's loads
 
         const int f = w / g.N, blk = w - f * g.N;
@@ -283,28 +264,26 @@ __global__ __launch_bounds__(64, 2) void k_me16(
         //   max(r - c, 0) = (|r - c| + r - c) / 2 per byte -> three v_sad_u8 per dword
         bool is_static = false;
         uint32_t s_c = 0;
-        if (MODE == kMe16Search) {
-            uint32_t s_d = 0;  // |r - c| + r - c = 2 * max(r - c, 0) per byte: never negative
+        uint32_t s_d = 0;  // |r - c| + r - c = 2 * max(r - c, 0) per byte: never negative
 #pragma unroll
-            for (int t = 0; t < 3; t++) {
-                s_d = __builtin_amdgcn_sad_u8(A.rv[t], A.cv[t], s_d);
-                s_d = __builtin_amdgcn_sad_u8(A.rv[t], 0u, s_d);
-                s_c = __builtin_amdgcn_sad_u8(A.cv[t], 0u, s_c);
-            }
-            // per lane: s_d holds sad(r,c) + sum(r); subtracting this lane's sum(c) keeps
-            // it >= 0, so one reduction gives 2 * sum(max(r - c, 0)) and one gives sum(c)
-            s_d = wave_sum_u32(s_d - s_c);
-            s_c = wave_sum_u32(s_c);  // sum of the current block's bytes
-            const uint32_t sdiff = s_d >> 1;
-            is_static = !g.never_static && sdiff <= g.thresh;
-            if (is_static && lane == 0) {
-                mv[2 * oidx + 0] = 0;
-                mv[2 * oidx + 1] = 0;
-                atomicAdd(&n_static[f], 1u);
+        for (int t = 0; t < 3; t++) {
+            s_d = __builtin_amdgcn_sad_u8(A.rv[t], A.cv[t], s_d);
+            s_d = __builtin_amdgcn_sad_u8(A.rv[t], 0u, s_d);
+            s_c = __builtin_amdgcn_sad_u8(A.cv[t], 0u, s_c);
+        }
+        // per lane: s_d holds sad(r,c) + sum(r); subtracting this lane's sum(c) keeps
+        // it >= 0, so one reduction gives 2 * sum(max(r - c, 0)) and one gives sum(c)
+        s_d = wave_sum_u32(s_d - s_c);
+        s_c = wave_sum_u32(s_c);  // sum of the current block's bytes
+        const uint32_t sdiff = s_d >> 1;
+        is_static = !g.never_static && sdiff <= g.thresh;
+        if (is_static && lane == 0) {
+            mv[2 * oidx + 0] = 0;
+            mv[2 * oidx + 1] = 0;
+            atomicAdd(&n_static[f], 1u);
 #ifndef VCS_ME16_STAMPS
-                if (cost_out) cost_out[oidx] = sdiff;
+            if (cost_out) cost_out[oidx] = sdiff;
 #endif
-            }
         }
         ME16_STAMP(1);  // static test (waits for this block's co-located loads)
         if (!is_static) {
@@ -317,13 +296,11 @@ __global__ __launch_bounds__(64, 2) void k_me16(
                 *(uint4 *)(s_win + row * kRowB + gi * 16) = v;
             }
             // ... and the negated current block next to it (pad byte -> 0xFF)
-            if (MODE == kMe16Search) {
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int e = lane + 64 * t, row = e / 13, j = e - row * 13;
-                    const uint32_t padm = ((j & 3) == 3 || j == 12) ? 0xFF000000u : 0u;
-                    if (e < 16 * 13) s_cur[row * 16 + j] = ~A.cq[t] | padm;
-                }
+            for (int t = 0; t < 4; t++) {
+                const int e = lane + 64 * t, row = e / 13, j = e - row * 13;
+                const uint32_t padm = ((j & 3) == 3 || j == 12) ? 0xFF000000u : 0u;
+                if (e < 16 * 13) s_cur[row * 16 + j] = ~A.cq[t] | padm;
             }
             wave_lds_fence();
             ME16_STAMP(2);  // window + current block parked (waits for this block's window loads)
@@ -345,40 +322,34 @@ __global__ __launch_bounds__(64, 2) void k_me16(
 
             uint32_t acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
             if (ncand > 64)  // wave-uniform
-                me16_rows<MODE, true, kRowB>(s_cur, p0, p1, acc0, acc1);
+                me16_rows<true, kRowB>(s_cur, p0, p1, acc0, acc1);
             else
-                me16_rows<MODE, false, kRowB>(s_cur, p0, p1, acc0, acc1);
+                me16_rows<false, kRowB>(s_cur, p0, p1, acc0, acc1);
 
             ME16_STAMP(3);  // the row loop
-            if (MODE == kMe16Sums) {
-                uint32_t *__restrict__ sb = sums + (size_t)blk * kMe16SumStride;
-                sb[cand0] = act0 ? acc0[0] + acc0[1] + acc0[2] + acc0[3] : 0u;
-                sb[cand1] = act1 ? acc1[0] + acc1[1] + acc1[2] + acc1[3] : 0u;
-            } else {
-                // cost = sum(r) - sum(c) + 256 * #{r < c}; 64 pad bytes always counted
-                const uint32_t n_lt0 = 768u + 64u - (acc0[0] + acc0[1] + acc0[2] + acc0[3]);
-                const uint32_t n_lt1 = 768u + 64u - (acc1[0] + acc1[1] + acc1[2] + acc1[3]);
-                const uint32_t cost0 = A.sr[0] + 256u * n_lt0 - s_c;
-                const uint32_t cost1 = A.sr[1] + 256u * n_lt1 - s_c;
-                uint32_t key = 0xFFFFFFFFu;  // (cost << 7) | raster index: motion.py:149
-                if (act0) key = (cost0 << 7) | (uint32_t)cand0;
-                if (act1) key = min(key, (cost1 << 7) | (uint32_t)cand1);
-                key = wave_min_u32(key);
-                if (lane == 0) {
-                    int bx = 0, by = 0;                    // motion.py:102
-                    unsigned long long c = 9999999999ull;  // motion.py:120
-                    if (key != 0xFFFFFFFFu) {
-                        const int cb = (int)(key & 127u);
-                        by = i_min + (cb / ncj) * STEP;
-                        bx = j_min + (cb % ncj) * STEP;
-                        c = key >> 7;
-                    }
-                    mv[2 * oidx + 0] = (int16_t)(bx - x);
-                    mv[2 * oidx + 1] = (int16_t)(by - y);
-#ifndef VCS_ME16_STAMPS
-                    if (cost_out) cost_out[oidx] = c;
-#endif
+            // cost = sum(r) - sum(c) + 256 * #{r < c}; 64 pad bytes always counted
+            const uint32_t n_lt0 = 768u + 64u - (acc0[0] + acc0[1] + acc0[2] + acc0[3]);
+            const uint32_t n_lt1 = 768u + 64u - (acc1[0] + acc1[1] + acc1[2] + acc1[3]);
+            const uint32_t cost0 = A.sr[0] + 256u * n_lt0 - s_c;
+            const uint32_t cost1 = A.sr[1] + 256u * n_lt1 - s_c;
+            uint32_t key = 0xFFFFFFFFu;  // (cost << 7) | raster index: motion.py:149
+            if (act0) key = (cost0 << 7) | (uint32_t)cand0;
+            if (act1) key = min(key, (cost1 << 7) | (uint32_t)cand1);
+            key = wave_min_u32(key);
+            if (lane == 0) {
+                int bx = 0, by = 0;                    // motion.py:102
+                unsigned long long c = 9999999999ull;  // motion.py:120
+                if (key != 0xFFFFFFFFu) {
+                    const int cb = (int)(key & 127u);
+                    by = i_min + (cb / ncj) * STEP;
+                    bx = j_min + (cb % ncj) * STEP;
+                    c = key >> 7;
                 }
+                mv[2 * oidx + 0] = (int16_t)(bx - x);
+                mv[2 * oidx + 1] = (int16_t)(by - y);
+#ifndef VCS_ME16_STAMPS
+                if (cost_out) cost_out[oidx] = c;
+#endif
             }
             wave_lds_fence();  // the window is rewritten by the next block
             ME16_STAMP(4);  // reduction + result store
@@ -389,9 +360,76 @@ __global__ __launch_bounds__(64, 2) void k_me16(
         ME16_STAMP(5);  // register hand-over
     }
 #ifdef VCS_ME16_STAMPS
-    if (MODE == kMe16Search && lane == 0 && cost_out)
+    if (lane == 0 && cost_out)
         for (int i = 0; i < 8; i++) cost_out[(size_t)blockIdx.x * 8 + i] = st_acc[i];
 #endif
+}
+
+// sum(r) table of one reference frame: sums[blk * 128 + cand] = byte sum of the
+// 16 x 16 block at candidate `cand` of block `blk` (what k_me16 / k_me16r add to
+// 256 * #{r < c} - sum(c)).  Separable instead of 100 block sums of 208 dwords:
+//   1. byte sum of every 5-pixel group of the window (64 rows x 13 groups) and of
+//      its first pixel -- four / one v_sad_u8 on the registers the loads return;
+//   2. candidate row sums S[row][cj] = three whole groups + the first pixel of the
+//      fourth (16 pixels from group cj on), 640 values;
+//   3. candidate sums = 16 consecutive S rows.
+// One wave per block, one block per workgroup (the latency of the 13 loads is
+// covered by occupancy, 9 KB of LDS per wave).  16 us for a 1080p frame against
+// 26 us for the row-loop form (k_me16 in sum mode, removed), once per GOP.
+__global__ __launch_bounds__(64) void k_me16_sums(const uint8_t *__restrict__ ref, Geom g,
+                                                  uint32_t *__restrict__ sums) {
+    constexpr int BS = 16, WIN = 32, STEP = 5, NG = kMe16Groups;
+    __shared__ uint32_t s_g[kMe16Rows * NG + 4];  // whole-group sums (+ slack for cj + 3 = 13)
+    __shared__ uint32_t s_p[kMe16Rows * NG + 4];  // first-pixel sums
+    __shared__ uint32_t s_S[kMe16Rows * 10];
+    const int lane = threadIdx.x, blk = blockIdx.x;
+    const int byi = blk / g.nbx, bxi = blk - byi * g.nbx;
+    const int x = bxi * BS, y = byi * BS;
+    const int i_min = max(y - WIN, 0), j_min = max(x - WIN, 0);
+    const uint8_t *__restrict__ wsrc = ref + (size_t)i_min * g.pitch + (size_t)(3 * j_min);
+    uint4 stg[NG];
+#pragma unroll
+    for (int t = 0; t < NG; t++) {
+        const int e = lane + 64 * t, row = e / NG, gi = e - row * NG;
+        stg[t] = load16_any_align(wsrc + (size_t)row * g.pitch + 15 * gi);
+    }
+#pragma unroll
+    for (int t = 0; t < NG; t++) {
+        const uint4 v = stg[t];
+        uint32_t a = __builtin_amdgcn_sad_u8(v.x, 0u, 0u);
+        a = __builtin_amdgcn_sad_u8(v.y, 0u, a);
+        a = __builtin_amdgcn_sad_u8(v.z, 0u, a);
+        a = __builtin_amdgcn_sad_u8(v.w & 0x00FFFFFFu, 0u, a);  // 15 bytes, not the pad
+        s_g[lane + 64 * t] = a;
+        s_p[lane + 64 * t] = __builtin_amdgcn_sad_u8(v.x & 0x00FFFFFFu, 0u, 0u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 10; q++) {
+        const int idx = lane + 64 * q, row = idx / 10, cj = idx - row * 10;
+        const uint32_t *gr = s_g + row * NG + cj;
+        s_S[idx] = gr[0] + gr[1] + gr[2] + s_p[row * NG + cj + 3];
+    }
+    __syncthreads();
+    // candidate grid exactly as in k_me16 (motion.py:132-140)
+    const int i_max = min(y + WIN, g.H), j_max = min(x + WIN, g.W);
+    const int ri = i_max - BS - i_min, rj = j_max - BS - j_min;
+    const int nci = ri >= 1 ? (ri - 1) / STEP + 1 : 0;
+    const int ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
+    const int ncand = nci * ncj;
+    uint32_t *__restrict__ sb = sums + (size_t)blk * kMe16SumStride;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int cand = lane + 64 * h;
+        uint32_t acc = 0;
+        if (cand < ncand) {
+            const int ci = cand / ncj, cj = cand - ci * ncj;
+            const uint32_t *col = s_S + (STEP * ci) * 10 + cj;
+#pragma unroll
+            for (int k = 0; k < BS; k++) acc += col[k * 10];
+        }
+        sb[cand] = acc;
+    }
 }
 
 // The fast kernel covers the reference's own parameters for block_size 16 on
@@ -421,9 +459,7 @@ inline int me16_grid(int cus, long long total) {
 // sum(r) table of `ref` (once per reference frame).
 inline int launch_me_fast_sums(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                                uint32_t *sums) {
-    dim3 gd(me16_grid(cus, g.N)), block(64);
-    hipLaunchKernelGGL((k_me16<18, kMe16Sums>), gd, block, 0, stream, ref, ref, (size_t)0, g, g.N, sums,
-                       (int16_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_me16_sums, dim3(g.N), dim3(64), 0, stream, ref, g, sums);
     return 0;
 }
 
@@ -441,7 +477,7 @@ inline int launch_me_fast(const Geom &g, hipStream_t stream, int cus, const uint
     hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * gd.x, stream);
     cost = dbg;
 #endif
-    hipLaunchKernelGGL((k_me16<18, kMe16Search>), gd, block, 0, stream, ref, curs, stride, g,
+    hipLaunchKernelGGL((k_me16<18>), gd, block, 0, stream, ref, curs, stride, g,
                        (int)total, sums, mv, ns, cost);
 #ifdef VCS_ME16_STAMPS
     {

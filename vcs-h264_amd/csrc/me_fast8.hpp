@@ -18,6 +18,8 @@
 
 namespace vcs {
 
+enum { kMe8Search = 0, kMe8Sums = 1 };  // k_me8<MODE>: motion search / the reference's sum(r) table
+
 constexpr int kMe8Rows = 32;     // 2 * win
 constexpr int kMe8Groups = 11;   // ceil(32 px / 3)
 constexpr int kMe8Slots = 24;    // 16-byte slots per LDS window row
@@ -63,7 +65,7 @@ __device__ __forceinline__ void me8_issue(const uint8_t *__restrict__ ref,
     const size_t blk_off = (size_t)y * g.pitch + (size_t)(24 * bxi);
     const int i_min = max(y - WIN, 0), j_min = max(x - WIN, 0);
     const uint8_t *__restrict__ wsrc = ref + (size_t)i_min * g.pitch + (size_t)(3 * j_min);
-    if (MODE == kMe16Search) {
+    if (MODE == kMe8Search) {
         const uint8_t *__restrict__ cblk = curs + (size_t)f * cur_stride + blk_off;
         const uint8_t *__restrict__ rblk = ref + blk_off;
         R.rv = *(const uint32_t *)(rblk + O.blk);
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(64, 3) void k_me8(
         // ---- static test (motion.py:109-116) over the 48 dwords of the block ------
         bool is_static = false;
         uint32_t s_c = 0;
-        if (MODE == kMe16Search) {
+        if (MODE == kMe8Search) {
             uint32_t s_d = 0;
             if (lane < 48) {
                 s_d = __builtin_amdgcn_sad_u8(A.rv, A.cv, 0u);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(64, 3) void k_me8(
                 v.w = 0u;
                 if (e < kMe8Rows * kMe8Groups) *(uint4 *)(s_win + row * kMe8RowB + gi * 16) = v;
             }
-            if (MODE == kMe16Search) {  // negated current block, pad / foreign bytes -> 0xFF
+            if (MODE == kMe8Search) {  // negated current block, pad / foreign bytes -> 0xFF
                 const int row = lane >> 3, q = lane & 7;
                 const int sl = q < 3 ? 0 : q < 6 ? 1 : 2, d = q - 3 * sl;
                 const uint32_t padm = d == 2 ? 0xFFFFFF00u : (sl == 2 && d == 1) ? 0xFFFF0000u : 0u;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(64, 3) void k_me8(
 #pragma unroll
             for (int m = 0; m < 3; m++) {
                 a[0][m] = ((const uint4 *)p)[m];
-                if (MODE == kMe16Search) c[0][m] = ((const uint4 *)s_cur)[m];
+                if (MODE == kMe8Search) c[0][m] = ((const uint4 *)s_cur)[m];
             }
 #pragma unroll
             for (int k = 0; k < BS; k++) {
@@ -203,17 +205,17 @@ __global__ __launch_bounds__(64, 3) void k_me8(
 #pragma unroll
                     for (int m = 0; m < 3; m++) {
                         a[nx2][m] = ((const uint4 *)(p + (k + 1) * kMe8RowB))[m];
-                        if (MODE == kMe16Search) c[nx2][m] = ((const uint4 *)(s_cur + (k + 1) * 12))[m];
+                        if (MODE == kMe8Search) c[nx2][m] = ((const uint4 *)(s_cur + (k + 1) * 12))[m];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (MODE == kMe16Search)
+                if (MODE == kMe8Search)
                     acc += me8_count8(a[cu][0], a[cu][1], a[cu][2], c[cu][0], c[cu][1], c[cu][2]);
                 else
                     acc += me8_sum8(a[cu][0], a[cu][1], a[cu][2]);
             }
 
-            if (MODE == kMe16Sums) {
+            if (MODE == kMe8Sums) {
                 sums[(size_t)blk * kMe8SumStride + lane] = act ? acc : 0u;
             } else {
                 // cost = sum(r) - sum(c) + 256 * #{r < c}; 64 pad bytes always counted
@@ -257,7 +259,7 @@ inline int me8_grid(int cus, long long total) {
 }
 inline int launch_me_fast8_sums(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                                 uint32_t *sums) {
-    hipLaunchKernelGGL((k_me8<kMe16Sums>), dim3(me8_grid(cus, g.N)), dim3(64), 0, stream, ref, ref,
+    hipLaunchKernelGGL((k_me8<kMe8Sums>), dim3(me8_grid(cus, g.N)), dim3(64), 0, stream, ref, ref,
                        (size_t)0, g, g.N, sums, (int16_t *)nullptr, (uint32_t *)nullptr,
                        (unsigned long long *)nullptr);
     return 0;
@@ -267,7 +269,7 @@ inline int launch_me_fast8(const Geom &g, hipStream_t stream, int cus, const uin
                            uint32_t *ns, unsigned long long *cost) {
     const long long total = (long long)g.N * n;
     if (total > 0x7FFFFFFF) return -1;
-    hipLaunchKernelGGL((k_me8<kMe16Search>), dim3(me8_grid(cus, total)), dim3(64), 0, stream, ref,
+    hipLaunchKernelGGL((k_me8<kMe8Search>), dim3(me8_grid(cus, total)), dim3(64), 0, stream, ref,
                        curs, stride, g, (int)total, sums, mv, ns, cost);
     return 0;
 }

@@ -63,19 +63,19 @@ __device__ __forceinline__ void me16r_offsets(const Geom &g, int lane, Me16rOffs
 // 16 rows of two candidates per lane out of the circular window.  base0/base1:
 // LDS byte offset of the candidate's first row; wrap0/wrap1: first row index
 // that lies past slot 63 (>= 16: never).  Otherwise as me16_rows.
-template <int MODE, bool TWO, int ROWB>
+template <bool TWO, int ROWB>
 __device__ __forceinline__ void me16r_rows(const uint8_t *s_win, const uint32_t *s_cur, int base0,
                                            int wrap0, int base1, int wrap1, uint32_t (&acc0)[4],
                                            uint32_t (&acc1)[4]) {
     Me16Q c[2], a[2], b[2];
-    if (MODE == kMe16Search) me16_ld(c[0], s_cur);
+    me16_ld(c[0], s_cur);
     me16_ld(a[0], s_win + base0);
     if (TWO) me16_ld(b[0], s_win + base1);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const int cur = k & 1, nxt = cur ^ 1;
         if (k + 1 < 16) {
-            if (MODE == kMe16Search) me16_ld(c[nxt], s_cur + (k + 1) * kMe16CurPitch);
+            me16_ld(c[nxt], s_cur + (k + 1) * kMe16CurPitch);
             const int o0 = base0 + (k + 1) * ROWB - ((k + 1) >= wrap0 ? 64 * ROWB : 0);
             me16_ld(a[nxt], s_win + o0);
             if (TWO) {
@@ -84,14 +84,8 @@ __device__ __forceinline__ void me16r_rows(const uint8_t *s_win, const uint32_t 
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (MODE == kMe16Search) {
-            me16_count13(a[cur], c[cur], acc0);
-            if (TWO) me16_count13(b[cur], c[cur], acc1);
-        } else {
-            me16_sum13(a[cur], acc0);
-            if (TWO) me16_sum13(b[cur], acc1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        me16_count13(a[cur], c[cur], acc0);
+        if (TWO) me16_count13(b[cur], c[cur], acc1);
     }
 }
 
@@ -152,7 +146,19 @@ __device__ __forceinline__ void me16r_slabs(const uint8_t *s_win, const uint32_t
     }
 }
 
-template <int MODE>
+// Empty kernel launched with one workgroup per CU right before k_me16r (launch_me_roll).
+// k_me16r deals its column segments statically, and at 29 x 1080p a wave gets 3 or 4 of
+// them; how long the kernel takes then depends on which two waves the dispatcher puts on
+// the same SIMD (a "4" beside a "3" is fine, two "4"s are not), and that placement depends
+// on where the previous dispatch left the workgroup dispatcher's per-CU state.  Measured
+// on MI355X, same binary: k_me16r takes 0.82-0.83 ms after a kernel of 8,040 short
+// workgroups, after a 1-workgroup kernel or after a memset, and 0.72-0.74 ms after any
+// dispatch that visits every CU (256 to 4,096 workgroups, empty or not).  Schemes that
+// do not depend on placement were measured too: equal-length runs in column-major order
+// 0.77-0.79 ms (the waves of an XCD no longer sweep adjacent columns in step), per-XCD
+// work queues 0.87 ms, the last round cut into shorter pieces 0.84 ms.
+__global__ void k_me16r_primer() {}
+
 __global__ __launch_bounds__(64, 2) void k_me16r(
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
     Geom g, int n_frames, int seg_len, uint32_t *__restrict__ sums, int16_t *__restrict__ mv,
@@ -205,24 +211,22 @@ __global__ __launch_bounds__(64, 2) void k_me16r(
 
       auto issue = [&](int byy, int Bwin, Me16rRegs &R) {
           const size_t blk_off = (size_t)(byy * BS) * g.pitch + (size_t)(48 * bxi);
-          if (MODE == kMe16Search) {
-              const uint8_t *__restrict__ cblk = curs + (size_t)f * cur_stride + blk_off;
-              const uint8_t *__restrict__ rblk = ref + blk_off;
+          const uint8_t *__restrict__ cblk = curs + (size_t)f * cur_stride + blk_off;
+          const uint8_t *__restrict__ rblk = ref + blk_off;
 #pragma unroll
-              for (int t = 0; t < 3; t++) {
-                  R.rv[t] = *(const uint32_t *)(rblk + O.blk[t]);
-                  R.cv[t] = *(const uint32_t *)(cblk + O.blk[t]);
-              }
-#pragma unroll
-              for (int t = 0; t < 4; t++) {
-                  uint32_t v;
-                  __builtin_memcpy(&v, cblk + O.cq[t], 4);
-                  R.cq[t] = v;
-              }
-              const uint32_t *__restrict__ sb = sums + (size_t)(byy * g.nbx + bxi) * kMe16SumStride;
-              R.sr[0] = sb[lane];
-              R.sr[1] = sb[lane + 64];
+          for (int t = 0; t < 3; t++) {
+              R.rv[t] = *(const uint32_t *)(rblk + O.blk[t]);
+              R.cv[t] = *(const uint32_t *)(cblk + O.blk[t]);
           }
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+              uint32_t v;
+              __builtin_memcpy(&v, cblk + O.cq[t], 4);
+              R.cq[t] = v;
+          }
+          const uint32_t *__restrict__ sb = sums + (size_t)(byy * g.nbx + bxi) * kMe16SumStride;
+          R.sr[0] = sb[lane];
+          R.sr[1] = sb[lane + 64];
           // rows Bwin + 64 .. Bwin + 79: what the next block down adds
           const uint8_t *__restrict__ nsrc = colbase + (size_t)(Bwin + 64) * g.pitch;
 #pragma unroll
@@ -246,35 +250,31 @@ __global__ __launch_bounds__(64, 2) void k_me16r(
         // ---- static test (motion.py:109-116), as in k_me16 ---------------------------
         bool is_static = false;
         uint32_t s_c = 0;
-        if (MODE == kMe16Search) {
-            uint32_t s_d = 0;
+        uint32_t s_d = 0;
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
-                s_d = __builtin_amdgcn_sad_u8(A.rv[q], A.cv[q], s_d);
-                s_d = __builtin_amdgcn_sad_u8(A.rv[q], 0u, s_d);
-                s_c = __builtin_amdgcn_sad_u8(A.cv[q], 0u, s_c);
-            }
-            s_d = wave_sum_u32(s_d - s_c);
-            s_c = wave_sum_u32(s_c);
-            const uint32_t sdiff = s_d >> 1;
-            is_static = !g.never_static && sdiff <= g.thresh;
-            if (is_static && lane == 0) {
-                mv[2 * oidx + 0] = 0;
-                mv[2 * oidx + 1] = 0;
-                atomicAdd(&n_static[f], 1u);
-                if (cost_out) cost_out[oidx] = sdiff;
-            }
+        for (int q = 0; q < 3; q++) {
+            s_d = __builtin_amdgcn_sad_u8(A.rv[q], A.cv[q], s_d);
+            s_d = __builtin_amdgcn_sad_u8(A.rv[q], 0u, s_d);
+            s_c = __builtin_amdgcn_sad_u8(A.cv[q], 0u, s_c);
+        }
+        s_d = wave_sum_u32(s_d - s_c);
+        s_c = wave_sum_u32(s_c);
+        const uint32_t sdiff = s_d >> 1;
+        is_static = !g.never_static && sdiff <= g.thresh;
+        if (is_static && lane == 0) {
+            mv[2 * oidx + 0] = 0;
+            mv[2 * oidx + 1] = 0;
+            atomicAdd(&n_static[f], 1u);
+            if (cost_out) cost_out[oidx] = sdiff;
         }
         if (!is_static) {
-            if (MODE == kMe16Search) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int e = lane + 64 * q, row = e / 13, j = e - row * 13;
-                    const uint32_t padm = ((j & 3) == 3 || j == 12) ? 0xFF000000u : 0u;
-                    if (e < 16 * 13) s_cur[row * kMe16CurPitch + j] = ~A.cq[q] | padm;
-                }
-                if (lane < kMe16Pass2Max) s_part[lane] = 0;
+            for (int q = 0; q < 4; q++) {
+                const int e = lane + 64 * q, row = e / 13, j = e - row * 13;
+                const uint32_t padm = ((j & 3) == 3 || j == 12) ? 0xFF000000u : 0u;
+                if (e < 16 * 13) s_cur[row * kMe16CurPitch + j] = ~A.cq[q] | padm;
             }
+            if (lane < kMe16Pass2Max) s_part[lane] = 0;
             wave_lds_fence();
 
             // ---- candidate grid (motion.py:132-140); i_min = B ---------------------
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(64, 2) void k_me16r(
             const int base0 = s0 * ROWB + cj0 * 16, base1 = s1 * ROWB + cj1 * 16;
 
             uint32_t acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
-            if (MODE == kMe16Search && ncand > 64) {
-                me16r_rows<MODE, false, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
+            if (ncand > 64) {
+                me16r_rows<false, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
                 if (ncand == 100)
                     me16r_slabs<ROWB, 5>(s_win, s_cur, s_part, B, 36, ncj, lane);
                 else
@@ -301,37 +301,31 @@ __global__ __launch_bounds__(64, 2) void k_me16r(
                 wave_lds_fence();
                 acc1[0] = s_part[min(lane, kMe16Pass2Max - 1)];
             } else if (ncand > 64) {
-                me16r_rows<MODE, true, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
+                me16r_rows<true, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
             } else {
-                me16r_rows<MODE, false, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
+                me16r_rows<false, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
             }
 
-            if (MODE == kMe16Sums) {
-                uint32_t *__restrict__ sb = sums + (size_t)(by * g.nbx + bxi) * kMe16SumStride;
-                sb[cand0] = act0 ? acc0[0] + acc0[1] + acc0[2] + acc0[3] : 0u;
-                sb[cand1] = act1 ? acc1[0] + acc1[1] + acc1[2] + acc1[3] : 0u;
-            } else {
-                const uint32_t n_lt0 = 768u + 64u - (acc0[0] + acc0[1] + acc0[2] + acc0[3]);
-                const uint32_t n_lt1 = 768u + 64u - (acc1[0] + acc1[1] + acc1[2] + acc1[3]);
-                const uint32_t cost0 = A.sr[0] + 256u * n_lt0 - s_c;
-                const uint32_t cost1 = A.sr[1] + 256u * n_lt1 - s_c;
-                uint32_t key = 0xFFFFFFFFu;
-                if (act0) key = (cost0 << 7) | (uint32_t)cand0;
-                if (act1) key = min(key, (cost1 << 7) | (uint32_t)cand1);
-                key = wave_min_u32(key);
-                if (lane == 0) {
-                    int bx = 0, byy = 0;
-                    unsigned long long c = 9999999999ull;
-                    if (key != 0xFFFFFFFFu) {
-                        const int cb = (int)(key & 127u);
-                        byy = i_min + (cb / ncj) * STEP;
-                        bx = j_min + (cb % ncj) * STEP;
-                        c = key >> 7;
-                    }
-                    mv[2 * oidx + 0] = (int16_t)(bx - x);
-                    mv[2 * oidx + 1] = (int16_t)(byy - y);
-                    if (cost_out) cost_out[oidx] = c;
+            const uint32_t n_lt0 = 768u + 64u - (acc0[0] + acc0[1] + acc0[2] + acc0[3]);
+            const uint32_t n_lt1 = 768u + 64u - (acc1[0] + acc1[1] + acc1[2] + acc1[3]);
+            const uint32_t cost0 = A.sr[0] + 256u * n_lt0 - s_c;
+            const uint32_t cost1 = A.sr[1] + 256u * n_lt1 - s_c;
+            uint32_t key = 0xFFFFFFFFu;
+            if (act0) key = (cost0 << 7) | (uint32_t)cand0;
+            if (act1) key = min(key, (cost1 << 7) | (uint32_t)cand1);
+            key = wave_min_u32(key);
+            if (lane == 0) {
+                int bx = 0, byy = 0;
+                unsigned long long c = 9999999999ull;
+                if (key != 0xFFFFFFFFu) {
+                    const int cb = (int)(key & 127u);
+                    byy = i_min + (cb / ncj) * STEP;
+                    bx = j_min + (cb % ncj) * STEP;
+                    c = key >> 7;
                 }
+                mv[2 * oidx + 0] = (int16_t)(bx - x);
+                mv[2 * oidx + 1] = (int16_t)(byy - y);
+                if (cost_out) cost_out[oidx] = c;
             }
             wave_lds_fence();  // all reads of this block's window are done
         }
@@ -389,7 +383,12 @@ inline int launch_me_roll(const Geom &g, hipStream_t stream, int cus, const uint
     const int seg = me16r_seg_len(g.nby);
     const long long units = (long long)n * ((g.nby + seg - 1) / seg) * g.nbx;
     dim3 gd(me16_grid(cus, units)), block(64);
-    hipLaunchKernelGGL((k_me16r<kMe16Search>), gd, block, 0, stream, ref, curs, stride, g, n, seg, sums,
+    static const bool primer = [] {
+        const char *e = getenv("VCS_ME16_PRIMER");  // 0 = off (A/B measurements)
+        return !(e && e[0] == '0');
+    }();
+    if (primer) hipLaunchKernelGGL(k_me16r_primer, dim3(cus), dim3(64), 0, stream);
+    hipLaunchKernelGGL(k_me16r, gd, block, 0, stream, ref, curs, stride, g, n, seg, sums,
                        mv, ns, cost);
     return 0;
 }
