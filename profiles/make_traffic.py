@@ -16,17 +16,22 @@ N = (H // BS) * (W // BS)
 ALG = {  # algorithmic bytes per launch (29 P frames)
     "k_me16r": FRAMES * (2 * F + 4 * N),
     "k_fdct<residual>": FRAMES * (10 * F + 4 * N),
-    "k_me16<sums>": F + N * 100 * 4,
+    "k_me16_sums": F + N * 128 * 4,
 }
-PMC_NAMES = {"vcs::k_me16r<0>": "k_me16r", "vcs::k_fdct<1, 0, true>": "k_fdct<residual>",
-             "vcs::k_me16<18, 1>": "k_me16<sums>"}
+PMC_PREFIX = {"vcs::k_me16r": "k_me16r", "vcs::k_fdct<1, 0,": "k_fdct<residual>",
+              "vcs::k_me16_sums": "k_me16_sums"}   # kernel-name prefixes in the PMC summary
 
 
 def main(path):
     pmc = json.load(open(path))
     kernels = {}
-    for pname, name in PMC_NAMES.items():
-        v = pmc[pname]
+    for prefix, name in PMC_PREFIX.items():
+        keys = [k for k in pmc if k.startswith(prefix) and "primer" not in k]
+        if len(keys) != 1:
+            sys.exit("expected one kernel starting with %r, found %r" % (prefix, keys))
+        v = pmc[keys[0]]
+        if name == "k_me16r":
+            sampled = int(v["dispatches_sampled"])
         fetch, write = int(v["FETCH_SIZE"] * 1024), int(v["WRITE_SIZE"] * 1024)
         corrected = 2 * fetch + write
         kernels[name] = {
@@ -44,13 +49,13 @@ def main(path):
                "%d dispatches.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B "
                "per 128-B request for wide coalesced reads, so it is doubled; WRITE_SIZE is exact "
                "(k_fdct: 29 x 3 x 1080 x 1920 x 8 B = 1,443,225,600 B).  Calibration in our own access "
-               "pattern: k_me16<18,sums> reads one 6.22 MB reference frame through 16-byte unaligned "
-               "window loads and reports FETCH_SIZE ~ 4.1 MB, less than the 6.22 MB it must read at "
-               "least once, i.e. the under-count applies to this pattern too.  k_fdct's 4-byte-per-lane "
+               "pattern: k_me16_sums reads one 6.22 MB reference frame through 16-byte unaligned "
+               "window loads; a raw FETCH_SIZE below the 6.22 MB it must read at least once shows that the "
+               "under-count applies to this pattern too.  k_fdct's 4-byte-per-lane "
                "pixel loads are uncalibrated: its read figure is an upper bound.  k_fdct's traffic is "
                "below its algorithmic bytes because the latter charge the reference frame once per P "
                "frame (SURVEY 8d) while the band-per-XCD strip mapping keeps it in L2."
-               % int(pmc["vcs::k_me16r<0>"]["dispatches_sampled"]),
+               % sampled,
         "source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)) + "/.."),
         "kernels": kernels,
     }
