@@ -197,7 +197,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.timing_enable(True)
+    ctx.timing_enable(not os.environ.get("VCS_BENCH_NO_EVENTS"))   # diagnostic: cost of the event brackets
     ctx.timing_reset()
     fence()
     t0 = time.perf_counter()
