@@ -382,7 +382,11 @@ __global__ __launch_bounds__(64) void k_me16_sums(const uint8_t *__restrict__ re
     __shared__ uint32_t s_g[kMe16Rows * NG + 4];  // whole-group sums (+ slack for cj + 3 = 13)
     __shared__ uint32_t s_p[kMe16Rows * NG + 4];  // first-pixel sums
     __shared__ uint32_t s_S[kMe16Rows * 10];
-    const int lane = threadIdx.x, blk = blockIdx.x;
+    // workgroups go round-robin to the 8 XCDs: give each XCD a contiguous run of blocks so that
+    // the 75 %-overlapping windows of neighbouring blocks meet in one L2 (grid = 8 * chunk)
+    const int lane = threadIdx.x, chunk = gridDim.x >> 3;
+    const int blk = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+    if (blk >= g.N) return;
     const int byi = blk / g.nbx, bxi = blk - byi * g.nbx;
     const int x = bxi * BS, y = byi * BS;
     const int i_min = max(y - WIN, 0), j_min = max(x - WIN, 0);
@@ -459,7 +463,7 @@ inline int me16_grid(int cus, long long total) {
 // sum(r) table of `ref` (once per reference frame).
 inline int launch_me_fast_sums(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                                uint32_t *sums) {
-    hipLaunchKernelGGL(k_me16_sums, dim3(g.N), dim3(64), 0, stream, ref, g, sums);
+    hipLaunchKernelGGL(k_me16_sums, dim3(8 * ((g.N + 7) / 8)), dim3(64), 0, stream, ref, g, sums);
     return 0;
 }
 

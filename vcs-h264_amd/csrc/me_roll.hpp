@@ -157,7 +157,11 @@ __device__ __forceinline__ void me16r_slabs(const uint8_t *s_win, const uint32_t
 // do not depend on placement were measured too: equal-length runs in column-major order
 // 0.77-0.79 ms (the waves of an XCD no longer sweep adjacent columns in step), per-XCD
 // work queues 0.87 ms, the last round cut into shorter pieces 0.84 ms.
-__global__ void k_me16r_primer() {}
+// It also zeroes the per-frame static-block counters k_me16r adds to (one memset less).
+__global__ void k_me16r_primer(uint32_t *__restrict__ n_static, int n_frames) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_frames; i += gridDim.x * blockDim.x)
+        n_static[i] = 0;
+}
 
 __global__ __launch_bounds__(64, 2) void k_me16r(
     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
@@ -384,10 +388,10 @@ inline int launch_me_roll(const Geom &g, hipStream_t stream, int cus, const uint
     const long long units = (long long)n * ((g.nby + seg - 1) / seg) * g.nbx;
     dim3 gd(me16_grid(cus, units)), block(64);
     static const bool primer = [] {
-        const char *e = getenv("VCS_ME16_PRIMER");  // 0 = off (A/B measurements)
+        const char *e = getenv("VCS_ME16_PRIMER");  // 0 = a single workgroup (A/B measurements)
         return !(e && e[0] == '0');
     }();
-    if (primer) hipLaunchKernelGGL(k_me16r_primer, dim3(cus), dim3(64), 0, stream);
+    hipLaunchKernelGGL(k_me16r_primer, dim3(primer ? cus : 1), dim3(64), 0, stream, ns, n);
     hipLaunchKernelGGL(k_me16r, gd, block, 0, stream, ref, curs, stride, g, n, seg, sums,
                        mv, ns, cost);
     return 0;

@@ -197,7 +197,9 @@ int launch_me_generic_t(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, siz
 int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride, int n,
               int16_t *mv, uint32_t *ns, unsigned long long *cost, bool force_generic = false) {
     if (c->g.N == 0 || n == 0) return VCS_OK;
-    HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
+    // the per-frame static-block counters start at zero; the rolling kernel's primer does it
+    const bool roll = c->me_fast_ok && !force_generic && me16r_worthwhile(c->g, c->cus, n);
+    if (!roll) HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
     EvPair ev;
     int rc = t_begin(c, VCS_T_ME, &ev);
     if (rc) return rc;
@@ -207,7 +209,7 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
             HIP_TRY(c, hipGetLastError());
             c->sums_valid = true;
         }
-        rc = me16r_worthwhile(c->g, c->cus, n)
+        rc = roll
                  ? launch_me_roll(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost)
                  : launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
