@@ -1,0 +1,60 @@
+// What can a kernel with k_fdct's traffic shape reach on this chip?  It reads 3 bytes per pixel
+// (unaligned dword per lane, 8 rows of a 64-pixel strip) and writes three float64 planes with the
+// same row-contiguous non-temporal stores, and computes nothing.   29 x 1080p per launch.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/ub_stream tools/ub_stream.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__global__ __launch_bounds__(64) void k_shape(const uint8_t *img, double *planes, int H, int W, int n) {
+    const int groups_x = W / 64, per_frame = groups_x * (H / 8);
+    const long long id = blockIdx.x;
+    const int f = (int)(id / per_frame), s = (int)(id - (long long)f * per_frame);
+    const int ty = s / groups_x, gx = s - ty * groups_x, lane = threadIdx.x;
+    const size_t F = (size_t)H * W * 3, plane = (size_t)H * W;
+    const uint8_t *src = img + f * F;
+    uint32_t px[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t v;
+        __builtin_memcpy(&v, src + (size_t)(ty * 8 + k) * W * 3 + 3 * (gx * 64 + lane), 4);
+        px[k] = v;
+    }
+    double *out = planes + (size_t)f * 3 * plane;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            const int e = s4 * 64 + lane, row = e >> 5, c2 = e & 31;
+            d2 v;
+            v.x = (double)((px[row] >> (8 * ch)) & 255u);
+            v.y = (double)((px[(row + 1) & 7] >> (8 * ch)) & 255u);
+            d2 *o = (d2 *)(out + ch * plane + (size_t)(ty * 8 + row) * W + gx * 64 + 2 * c2);
+            if (NT) __builtin_nontemporal_store(v, o); else *o = v;
+        }
+}
+int main() {
+    const int H = 1080, W = 1920, n = 29;
+    const size_t F = (size_t)H * W * 3;
+    uint8_t *img; double *planes;
+    hipMalloc(&img, F * n + 64); hipMalloc(&planes, F * n * 8);
+    hipMemset(img, 7, F * n + 64);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const unsigned grid = (unsigned)((W / 64) * (H / 8) * n);
+    for (int nt = 0; nt < 2; nt++) {
+        float best = 1e9f;
+        for (int it = 0; it < 12; it++) {
+            hipEventRecord(a);
+            if (nt) hipLaunchKernelGGL(k_shape<true>, dim3(grid), dim3(64), 0, 0, img, planes, H, W, n);
+            else hipLaunchKernelGGL(k_shape<false>, dim3(grid), dim3(64), 0, 0, img, planes, H, W, n);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (it > 1 && ms < best) best = ms;
+        }
+        const double bytes = (double)F * n * 9;  // 1 read + 8 written per pixel byte
+        printf("shape kernel, %s stores: %.3f ms  %.0f GB/s (reads + writes)\n", nt ? "non-temporal" : "plain",
+               best, bytes / best / 1e6);
+    }
+    return 0;
+}
