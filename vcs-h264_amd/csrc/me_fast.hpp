@@ -17,8 +17,8 @@
 //   * sum(r) does not depend on the current frame.  Every P frame of a GOP is
 //     searched against the same raw I frame (encoder.py:51-52), so the byte
 //     sum of each (block, candidate) reference patch is computed ONCE per
-//     reference frame (k_me16<.., kSums>, 100 x uint32 per block) and read
-//     back by the search: the row loop holds no v_sad_u8 at all.
+//     reference frame (k_me16_sums, 100 x uint32 per block) and read back by
+//     the search: the row loop holds no v_sad_u8 at all.
 //   * The current block is wave-uniform.  Its 16 rows are re-packed once per
 //     block into the same 5-pixel-group format (negated, pad byte 0xFF), lane-
 //     parallel, parked in 1 KB of LDS and read back with wave-uniform

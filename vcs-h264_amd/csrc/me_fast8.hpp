@@ -8,7 +8,7 @@
 //     which 8 dwords carry the 24 bytes of the row.
 //   * cost = sum(r) - sum(c) + 256 * #{r < c}: #{r >= c} from bit 7 of
 //     v_lerp_u8(r, ~c, 1), pad / foreign bytes neutralised by ~c = 0xFF;
-//     sum(r) from a per-reference table (k_me8<.., kSums>).
+//     sum(r) from a per-reference table (k_me8<kMe8Sums>).
 //   * lane = candidate: an interior block has exactly 8 x 8 = 64 candidates,
 //     one full wave, one pass.  LDS row pitch 24 slots: slot = 24*(3ci + k) + cj
 //     == 8ci + cj + 8k (mod 16) = lane + 8k: conflict-free ds_read_b128.
