@@ -109,46 +109,51 @@ def main():
     N, F = ctx.N, ctx.F
     # this rank's slice of the (long) GOP; synthetic, deterministic
     ref, frames = synth_gop(H, W, n, seed=1234, first=1 + rank * n)
+    overlap = use_dist and not args.serial_comm
     ctx.gop_reserve(n, with_decode=args.with_decode)
     ctx.gop_upload(0, frames)
-    overlap = False
     if use_dist:
-        ptr, nb = ctx.dev_ptr(0)
-        t_ref = torch.as_tensor(_DevBytes(ptr, nb), device="cuda")
-        ptr, nb = ctx.dev_ptr(1)
-        t_mv = torch.as_tensor(_DevBytes(ptr, nb), device="cuda")
         if rank == 0:
             ctx.set_ref(ref)        # the I frame enters HBM on rank 0 only
         ctx.ref_written()
-        ctx.sync()
-        overlap = not args.serial_comm
+        ptr, nb = ctx.dev_ptr(1)
+        t_mv = torch.as_tensor(_DevBytes(ptr, nb), device="cuda")
+        ptr, nb = ctx.dev_ptr(0)
+        t_ref = torch.as_tensor(_DevBytes(ptr, nb), device="cuda")
         if overlap:
             # Collectives on their own stream, kernels on the context's stream, ordered by
-            # events only: the I frame of GOP k+1 is broadcast (into a staging buffer) while
-            # GOP k is being encoded, and GOP k's motion vectors are gathered (from a staging
-            # copy) while GOP k+1 is being encoded.  Every rank enqueues the collectives in
-            # the same order: bcast(0), bcast(1), gather(0), bcast(2), gather(1), ...
+            # events only.  GOP k uses reference buffer k & 1: the I frame of GOP k+1 is
+            # broadcast into the other one while GOP k is being encoded (vcs_ref_swap then makes
+            # it current, no copy).  GOP k's motion vectors are copied aside on the collectives'
+            # stream as soon as its kernels are done (1 MB) and gathered from there while GOP k+1
+            # is encoded into the same slots (writing the coefficient planes of alternate GOPs to
+            # alternate HBM regions costs the tail kernel 35 %, measured; so the slots stay put).
+            # Every rank enqueues the collectives in the same order:
+            # bcast(0), bcast(1), gather(0), bcast(2), gather(1), ...
+            ptr, nb = ctx.dev_ptr(3)
+            t_refs = [t_ref, torch.as_tensor(_DevBytes(ptr, nb), device="cuda")]
+            ctx.sync()
+            t_refs[1].copy_(t_refs[0])               # rank 0: both hold the decoder's output
             xs = torch.cuda.ExternalStream(ctx.stream_handle(), device=torch.device("cuda", local_rank))
             cs = torch.cuda.Stream()
-            ref_stage = [t_ref.clone(), t_ref.clone()]   # rank 0: the decoder's output; others: filled by bcast
             mv_stage = [torch.empty_like(t_mv), torch.empty_like(t_mv)]
             t_all = [torch.empty(world * t_mv.numel(), dtype=torch.uint8, device="cuda") for _ in range(2)]
-            ev_b = [torch.cuda.Event(), torch.cuda.Event()]   # broadcast into ref_stage[i] done   (cs)
-            ev_r = [torch.cuda.Event(), torch.cuda.Event()]   # ref_stage[i] copied to the context (xs)
-            ev_c = [torch.cuda.Event(), torch.cuda.Event()]   # kernels + copy into mv_stage[i]    (xs)
-            ev_g = [torch.cuda.Event(), torch.cuda.Event()]   # gather out of mv_stage[i] done     (cs)
+            ev_b = [torch.cuda.Event(), torch.cuda.Event()]   # broadcast into reference buffer i done (cs)
+            ev_c = [torch.cuda.Event(), torch.cuda.Event()]   # kernels of GOP k (k & 1 = i) done       (xs)
+            ev_s = torch.cuda.Event()                         # the last GOP's vectors are copied aside (cs)
             torch.cuda.synchronize()
             state = {"k": 0}
 
             def issue_bcast(k):
                 i = k & 1
                 with torch.cuda.stream(cs):
-                    cs.wait_event(ev_r[i])           # GOP k-2 has taken its frame out of the buffer
-                    dist.broadcast(ref_stage[i], src=0)
+                    cs.wait_event(ev_c[i])           # GOP k-2 no longer reads this reference buffer
+                    dist.broadcast(t_refs[i], src=0)
                     ev_b[i].record(cs)
 
             issue_bcast(0)
         else:
+            ctx.sync()
             t_all = torch.empty(world * t_mv.numel(), dtype=torch.uint8, device="cuda")
     else:
         ctx.set_ref(ref)
@@ -158,21 +163,23 @@ def main():
             k = state["k"]
             i = k & 1
             state["k"] = k + 1
-            issue_bcast(k + 1)                       # next GOP's I frame, behind this GOP's kernels
-            xs.wait_event(ev_b[i])                   # this GOP's I frame has arrived
-            xs.wait_event(ev_g[i])                   # GOP k-2's vectors have left mv_stage[i]
-            with torch.cuda.stream(xs):
-                t_ref.copy_(ref_stage[i], non_blocking=True)
-                ev_r[i].record(xs)
-            ctx.ref_written()
+            issue_bcast(k + 1)                       # next GOP's I frame, beside this GOP's kernels
+            if k:
+                # one cross-stream wait per GOP (each costs ~15 us of queue latency): the copy of
+                # the previous GOP's vectors was enqueued behind this GOP's broadcast, so its
+                # event covers both "I frame has arrived" and "vectors copied aside"
+                xs.wait_event(ev_s)
+                ctx.ref_swap()                       # buffer i becomes the reference (new sum table)
+            else:
+                xs.wait_event(ev_b[i])
+                ctx.ref_written()
             ctx.gop_encode(0, n)                     # ME kernel + fused tail kernel
-            with torch.cuda.stream(xs):
-                mv_stage[i].copy_(t_mv, non_blocking=True)
-                ev_c[i].record(xs)
+            ev_c[i].record(xs)
             with torch.cuda.stream(cs):
                 cs.wait_event(ev_c[i])
+                mv_stage[i].copy_(t_mv, non_blocking=True)
+                ev_s.record(cs)
                 dist.all_gather_into_tensor(t_all[i], mv_stage[i])   # motion-vector collection
-                ev_g[i].record(cs)
             return
         if use_dist:
             ts = torch.cuda.current_stream().cuda_stream

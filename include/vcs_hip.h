@@ -160,11 +160,19 @@ int vcs_sync(vcs_ctx *ctx);
  * frame, gather of motion vectors): raw HBM pointers of the context's
  * resident buffers, valid until the context is destroyed / re-reserved.
  * which: 0 = reference frame (F bytes), 1 = GOP motion vectors
- * (n_slots*N*2 int16), 2 = GOP static counts (n_slots uint32).              */
+ * (n_slots*N*2 int16), 2 = GOP static counts (n_slots uint32), 3 = the
+ * alternate reference buffer (F bytes; allocated by the first request).      */
 int vcs_dev_ptr(vcs_ctx *ctx, int which, void **ptr, size_t *bytes);
 /* Marks the resident reference as valid after it was written through
  * vcs_dev_ptr(ctx, 0, ...) by a collective.                                 */
 int vcs_ref_written(vcs_ctx *ctx);
+/* Exchanges the current and the alternate reference buffer (pointer swap on
+ * the host, no GPU work) and marks the new current one as written: the next
+ * GOP's I frame can be broadcast into the alternate buffer while this GOP is
+ * still being encoded against the current one.  Work already enqueued keeps
+ * the buffer it was launched with.  After a swap, vcs_dev_ptr(0 / 3) return
+ * the exchanged pointers.                                                    */
+int vcs_ref_swap(vcs_ctx *ctx);
 
 /* ---- intra prediction (next row N1; BASELINE config 5) ------------------ */
 /* IntraframeCompression/intraframe.py: luma4x4 (:24-151), luma16x16 (:153-225)

@@ -174,6 +174,29 @@ def test_golden_real_small(vh, nm):
                 assert np.array_equal(c.decode_p(mv, planes), g[nm + "_full16"])
 
 
+def test_ref_swap_alternates_two_resident_references(vh, oracle):
+    """vcs_ref_swap: two resident reference buffers (the multi-GPU host layer broadcasts the
+    next GOP's I frame into the alternate one); each keeps its content and its own sum table."""
+    from synth import synth_v1
+    refA, cur = synth_v1(96, 128, seed=21)
+    refB = np.roll(refA, (3, -5), axis=(0, 1))
+    wantA, _ = oracle.me(cur, refA, 16)
+    wantB, _ = oracle.me(cur, refB, 16)
+    assert not np.array_equal(wantA, wantB)
+    with vh.Context(96, 128, 16) as c:
+        c.set_ref(refA)
+        assert np.array_equal(c.me(cur)[0], wantA)
+        p_cur, _ = c.dev_ptr(0)
+        p_alt, _ = c.dev_ptr(3)
+        c.ref_swap()                      # current: the (zeroed) alternate buffer
+        assert c.dev_ptr(0)[0] == p_alt and c.dev_ptr(3)[0] == p_cur
+        c.set_ref(refB)
+        assert np.array_equal(c.me(cur)[0], wantB)
+        for want in (wantA, wantB, wantA):
+            c.ref_swap()
+            assert np.array_equal(c.me(cur)[0], want)
+
+
 def _psnr(a, b):
     mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
     return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)

@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <utility>
+
 #include "../../include/vcs_hip.h"
 #include "dct_kernels.hpp"
 #include "intra_kernels.hpp"
@@ -47,6 +49,7 @@ struct vcs_ctx {
     int cus = 256;         // compute units of the device
     // single-frame buffers
     uint8_t *d_ref = nullptr, *d_cur = nullptr, *d_a = nullptr, *d_b = nullptr;
+    uint8_t *d_ref_alt = nullptr;  // second reference buffer (vcs_ref_swap), allocated on demand
     int16_t *d_mv = nullptr;
     int32_t *d_coords = nullptr;
     unsigned long long *d_cost = nullptr;
@@ -496,7 +499,7 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto &p : c->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     free_gop(c);
-    hipFree(c->d_ref); hipFree(c->d_cur); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_mv);
+    hipFree(c->d_ref); hipFree(c->d_ref_alt); hipFree(c->d_cur); hipFree(c->d_a); hipFree(c->d_b); hipFree(c->d_mv);
     hipFree(c->d_coords); hipFree(c->d_cost); hipFree(c->d_ns); hipFree(c->d_planes);
     hipFree(c->d_DQ);
     hipFree(c->d_sums);
@@ -904,6 +907,16 @@ int vcs_sync(vcs_ctx *c) {
     return VCS_OK;
 }
 
+// same size and slack as d_ref (k_me16's unclamped window rows), zeroed
+static int ensure_ref_alt(vcs_ctx *c) {
+    if (c->d_ref_alt) return VCS_OK;
+    const size_t bytes = c->Fs + me_fast_ref_slack(c->g);
+    HIP_TRY(c, hipMalloc(&c->d_ref_alt, bytes));
+    HIP_TRY(c, hipMemsetAsync(c->d_ref_alt, 0, bytes, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
 int vcs_dev_ptr(vcs_ctx *c, int which, void **ptr, size_t *bytes) {
     int rc = use(c);
     if (rc) return rc;
@@ -914,6 +927,10 @@ int vcs_dev_ptr(vcs_ctx *c, int which, void **ptr, size_t *bytes) {
         case 0: p = c->d_ref; b = c->F; break;
         case 1: p = c->g_mv; b = nmv * 4 * c->slots; break;
         case 2: p = c->g_ns; b = sizeof(uint32_t) * c->slots; break;
+        case 3:
+            if ((rc = ensure_ref_alt(c))) return rc;
+            p = c->d_ref_alt; b = c->F;
+            break;
         default: return fail(c, VCS_E_ARG, "bad buffer id %d", which);
     }
     if (!p) return fail(c, VCS_E_STATE, "buffer %d not allocated (vcs_gop_reserve first)", which);
@@ -925,6 +942,15 @@ int vcs_dev_ptr(vcs_ctx *c, int which, void **ptr, size_t *bytes) {
 int vcs_ref_written(vcs_ctx *c) {
     int rc = use(c);
     if (rc) return rc;
+    c->ref_valid = true;
+    c->sums_valid = false;
+    return VCS_OK;
+}
+
+int vcs_ref_swap(vcs_ctx *c) {
+    int rc = use(c);
+    if (rc || (rc = ensure_ref_alt(c))) return rc;
+    std::swap(c->d_ref, c->d_ref_alt);
     c->ref_valid = true;
     c->sums_valid = false;
     return VCS_OK;

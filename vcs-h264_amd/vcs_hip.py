@@ -66,6 +66,7 @@ SIGNATURES = {
     "vcs_stream_wait": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_signal": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_handle": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_void_p)]),
+    "vcs_ref_swap": (ctypes.c_int, [_c_ctx]),
     "vcs_timing_enable": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
     "vcs_timing_reset": (ctypes.c_int, [_c_ctx]),
     "vcs_timing": (ctypes.c_int, [_c_ctx, _f64p, _u64p, ctypes.c_int]),
@@ -405,6 +406,10 @@ class Context:
 
     def ref_written(self):
         self._ck(self._lib.vcs_ref_written(self._h))
+
+    def ref_swap(self):
+        """Exchange the current and the alternate reference buffer (dev_ptr 0 <-> 3)."""
+        self._ck(self._lib.vcs_ref_swap(self._h))
 
     def stream_wait(self, foreign_stream):
         """Our stream waits for `foreign_stream` (a hipStream_t as int; 0 = default)."""
