@@ -124,9 +124,8 @@ def main():
             # Collectives on their own stream, kernels on the context's stream, ordered by
             # events only.  GOP k uses reference buffer k & 1: the I frame of GOP k+1 is
             # broadcast into the other one while GOP k is being encoded (vcs_ref_swap then makes
-            # it current, no copy).  GOP k's motion vectors are copied aside on the collectives'
-            # stream as soon as its kernels are done (1 MB) and gathered from there while GOP k+1
-            # is encoded into the same slots (writing the coefficient planes of alternate GOPs to
+            # it current, no copy).  GOP k's motion vectors are copied aside behind its kernels
+            # (1 MB) and gathered from there while GOP k+1 is encoded into the same slots (writing the coefficient planes of alternate GOPs to
             # alternate HBM regions costs the tail kernel 35 %, measured; so the slots stay put).
             # Every rank enqueues the collectives in the same order:
             # bcast(0), bcast(1), gather(0), bcast(2), gather(1), ...
@@ -139,8 +138,7 @@ def main():
             mv_stage = [torch.empty_like(t_mv), torch.empty_like(t_mv)]
             t_all = [torch.empty(world * t_mv.numel(), dtype=torch.uint8, device="cuda") for _ in range(2)]
             ev_b = [torch.cuda.Event(), torch.cuda.Event()]   # broadcast into reference buffer i done (cs)
-            ev_c = [torch.cuda.Event(), torch.cuda.Event()]   # kernels of GOP k (k & 1 = i) done       (xs)
-            ev_s = torch.cuda.Event()                         # the last GOP's vectors are copied aside (cs)
+            ev_c = [torch.cuda.Event(), torch.cuda.Event()]   # kernels of GOP k (k & 1 = i) + copy done (xs)
             torch.cuda.synchronize()
             state = {"k": 0}
 
@@ -164,21 +162,23 @@ def main():
             i = k & 1
             state["k"] = k + 1
             issue_bcast(k + 1)                       # next GOP's I frame, beside this GOP's kernels
+            # One wait per GOP, on an event that was signalled long ago (during the previous GOP's
+            # kernels): this GOP's I frame has arrived -- and, since the collectives run in order
+            # on their stream and gather(k-2) was enqueued before bcast(k), GOP k-2's vectors
+            # have left mv_stage[i].  (A wait on something that has only just finished costs the
+            # kernels' stream ~20 us of queue latency: tried with the vector copy on the other
+            # stream.)
+            xs.wait_event(ev_b[i])
             if k:
-                # one cross-stream wait per GOP (each costs ~15 us of queue latency): the copy of
-                # the previous GOP's vectors was enqueued behind this GOP's broadcast, so its
-                # event covers both "I frame has arrived" and "vectors copied aside"
-                xs.wait_event(ev_s)
                 ctx.ref_swap()                       # buffer i becomes the reference (new sum table)
             else:
-                xs.wait_event(ev_b[i])
                 ctx.ref_written()
             ctx.gop_encode(0, n)                     # ME kernel + fused tail kernel
-            ev_c[i].record(xs)
+            with torch.cuda.stream(xs):
+                mv_stage[i].copy_(t_mv, non_blocking=True)   # 1 MB aside: GOP k+1 reuses the slots
+                ev_c[i].record(xs)
             with torch.cuda.stream(cs):
                 cs.wait_event(ev_c[i])
-                mv_stage[i].copy_(t_mv, non_blocking=True)
-                ev_s.record(cs)
                 dist.all_gather_into_tensor(t_all[i], mv_stage[i])   # motion-vector collection
             return
         if use_dist:
@@ -210,6 +210,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0                 # host time to enqueue the K steps
     fence()
     dt = time.perf_counter() - t0
     ms, launches = ctx.timing()
@@ -271,6 +272,7 @@ def main():
                                        "RCCL broadcast (I frame) + all-gather (vectors) per GOP, " +
                                        ("overlapped with the neighbouring GOPs' kernels" if overlap
                                         else "in sequence with the kernels"))},
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "kernel_ms_per_step": {"me": round(ms[vcs_hip.T_ME] / args.steps, 4),
                                    "enc_tail": round(ms[vcs_hip.T_ENC_TAIL] / args.steps, 4)},
             "roofline": roof(dom),
