@@ -596,6 +596,17 @@ def test_gop_1080p_rolling_kernel(vh, oracle):
             assert ns[k] == ons
         _, oplanes, _ = oracle.encode_p(frames[n - 1], ref, 16)
         assert np.array_equal(c.gop_get_planes(n - 1), oplanes)
+        # a second pass over the same slots, with frames the static test accepts: the
+        # per-frame static counters restart from zero (k_me16r's primer zeroes them)
+        frames2 = frames.copy()
+        frames2[3] = ref
+        frames2[7] = ref
+        c.gop_upload(0, frames2)
+        c.gop_encode(0, n)
+        mv2, ns2 = c.gop_get_mv(0, n)
+        assert ns2[3] == c.N and ns2[7] == c.N and not mv2[3].any()
+        keep = [k for k in range(n) if k not in (3, 7)]
+        assert np.array_equal(ns2[keep], ns[keep]) and np.array_equal(mv2[keep], mv[keep])
 
 
 def test_forced_kernel_variants_subprocess():
