@@ -185,6 +185,12 @@ int vcs_intra_luma16x16(vcs_ctx *ctx, const uint8_t *Y, double *res, double *pre
 int vcs_intra_chroma8x8(vcs_ctx *ctx, const uint8_t *Cr, const uint8_t *Cb, double *crres,
                         double *crpred, double *cbres, double *cbpred, double *modes);
 
+/* The 4x4 integer core transform the reference keeps commented out behind its intra
+ * prediction (intraframe.py:14-17, :352-358): out = np.round(C . X . C^T) per 4x4 block
+ * of a float64 H x W residual plane (H, W multiples of 4).  No running upstream code
+ * pins it; exact for integer-valued input.                                      */
+int vcs_intra_transform4x4(vcs_ctx *ctx, const double *res, double *out);
+
 /* GPU-side ordering against a foreign HIP stream (the stream torch / RCCL
  * collectives run on), without host synchronisation:
  *   vcs_stream_wait:   work enqueued on the context's stream after this call

@@ -262,6 +262,17 @@ def intra_chroma8x8(Cr, Cb):
     return out[0], out[1], out[2], out[3], modes
 
 
+def intra_transform4x4(X):
+    """intraframe.py:352-358 (commented out upstream): np.round(C . X . C^T) per 4x4 block."""
+    X = _c(X, np.float64)
+    H, W = X.shape
+    out = np.zeros((H, W))
+    rc = lib().vcso_intra_transform4x4(_p(X, _f64p), H, W, _p(out, _f64p))
+    if rc:
+        raise ValueError("transform4x4 needs H, W multiples of 4")
+    return out
+
+
 def set_threads(n):
     """OpenMP thread count for the cpu_baseline timing (bench.py)."""
     os.environ["OMP_NUM_THREADS"] = str(n)

@@ -601,3 +601,29 @@ int vcso_intra_chroma8x8(const uint8_t *Cr, const uint8_t *Cb, int H, int W, dou
         }
     return 0;
 }
+
+/* intraframe.py:352-358 (commented out upstream) with DCTTransform of :14-17:
+ * out = np.round(C . X . C^T) per 4x4 block.  np.matmul promotes C to float64. */
+int vcso_intra_transform4x4(const double *X, int H, int W, double *out) {
+    static const double C[4][4] = {{1, 1, 1, 1}, {2, 1, -1, -2}, {1, -1, -1, 1}, {1, -2, 2, -1}};
+    if (H % 4 || W % 4) return -1;
+#pragma omp parallel for schedule(static)
+    for (int by = 0; by < H / 4; by++)
+        for (int bx = 0; bx < W / 4; bx++) {
+            const double *x = X + (size_t)(4 * by) * W + 4 * bx;
+            double t[4][4];
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) {
+                    double a = 0.0;
+                    for (int k = 0; k < 4; k++) a += C[i][k] * x[(size_t)k * W + j];
+                    t[i][j] = a;
+                }
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++) {
+                    double a = 0.0;
+                    for (int k = 0; k < 4; k++) a += t[i][k] * C[j][k];
+                    out[(size_t)(4 * by + i) * W + 4 * bx + j] = rint(a);  /* np.round: half to even */
+                }
+        }
+    return 0;
+}

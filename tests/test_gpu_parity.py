@@ -496,6 +496,32 @@ def test_intra_1080p_vs_oracle(vh, oracle):
         got, want = c.intra_chroma(planes[1], planes[2]), oracle.intra_chroma8x8(planes[1], planes[2])
         for a, b in zip(got, want):
             assert np.array_equal(a, b)
+        # "+ DCT" of config 5: the 4x4 integer core transform of the luma residual
+        # (commented out upstream, intraframe.py:352-358 -- parity by arithmetic only)
+        yres = c.intra_luma(planes[0], 4)[0]
+        coef = c.intra_transform4x4(yres)
+        assert np.array_equal(coef, oracle.intra_transform4x4(yres))
+        C = np.array([[1, 1, 1, 1], [2, 1, -1, -2], [1, -1, -1, 1], [1, -2, 2, -1]])
+        blk = yres[8:12, 20:24]
+        assert np.array_equal(coef[8:12, 20:24], np.round(np.matmul(np.matmul(C, blk), C.transpose())))
+
+
+def test_intra_transform_dropin(vh):
+    sys_path = __import__("sys").path
+    idir = __import__("os").path.join(__import__("conftest").PKG, "IntraframeCompression")
+    if idir not in sys_path:
+        sys_path.insert(0, idir)
+    import intraframe as I
+    rng = np.random.default_rng(8)
+    Yres = rng.integers(-255, 256, (24, 40)).astype(np.float64)
+    want = np.zeros_like(Yres)
+    for i in range(0, 24, 4):          # the reference's commented-out loop, verbatim semantics
+        for j in range(0, 40, 4):
+            t = np.matmul(I.DCTTransform, Yres[i:i + 4, j:j + 4])
+            want[i:i + 4, j:j + 4] = np.round(np.matmul(t, I.DCTTransform.transpose()))
+    assert np.array_equal(I.transform4x4(Yres), want)
+    with pytest.raises(Exception):
+        I.transform4x4(np.zeros((6, 8)))
 
 
 def test_empty_and_tiny_frames(vh, oracle):

@@ -135,3 +135,17 @@ def test_intra_small(oracle, sfx):
     assert np.array_equal(modes, g["c8_modes" + sfx])
     assert np.array_equal(crpred, g["c8_crpred" + sfx]) and np.array_equal(crres, g["c8_crres" + sfx])
     assert np.array_equal(cbpred, g["c8_cbpred" + sfx]) and np.array_equal(cbres, g["c8_cbres" + sfx])
+
+
+def test_intra_transform4x4_matches_numpy(oracle):
+    """The commented-out 4x4 integer transform of intraframe.py:352-358, restated with the
+    same NumPy calls (no running upstream code: parity by arithmetic only)."""
+    rng = np.random.default_rng(5)
+    C = np.array([[1, 1, 1, 1], [2, 1, -1, -2], [1, -1, -1, 1], [1, -2, 2, -1]])
+    X = rng.integers(-255, 256, (32, 48)).astype(np.float64)
+    want = np.zeros_like(X)
+    for i in range(0, 32, 4):
+        for j in range(0, 48, 4):
+            t = np.matmul(C, X[i:i + 4, j:j + 4])
+            want[i:i + 4, j:j + 4] = np.round(np.matmul(t, C.transpose()))
+    assert np.array_equal(oracle.intra_transform4x4(X), want)

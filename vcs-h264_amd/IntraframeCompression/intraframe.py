@@ -7,9 +7,12 @@ intramodes.py predictors run as HIP kernels (libvcs_hip.so, no CPU fallback).
 Results are bit-identical to the reference's under NumPy 2 (its uint8 wrap
 quirks included) -- tests/golden/intra_small.npz.
 
-The reference module also runs a matplotlib demo at import and keeps 4x4
-integer-transform matrices that its own code never applies (:14-22, :352-358);
-neither is part of this path.
+The reference module also runs a matplotlib demo at import (not part of this
+path) and keeps the 4x4 integer core-transform matrices together with a
+commented-out loop that would apply them to the luma residual (:14-22,
+:352-358).  `transform4x4` below is that loop as a kernel; nothing upstream
+runs it, so its parity is pinned only by arithmetic (exact for the
+integer-valued residuals the predictors produce), not by a reference output.
 """
 import os
 import sys
@@ -27,6 +30,15 @@ blockw = 4
 blockh = 4
 blocksize = 4
 
+DCTTransform = np.array([[1, 1, 1, 1],          # intraframe.py:14-17
+                         [2, 1, -1, -2],
+                         [1, -1, -1, 1],
+                         [1, -2, 2, -1]])
+IDCTTransform = np.array([[1, 1, 1, 0.5],       # intraframe.py:19-22 (kept for completeness,
+                          [1, 0.5, -1, -1],     # unused upstream as well)
+                          [1, -0.5, -1, 1],
+                          [1, -1, 1, -0.5]])
+
 
 def _plane(a, name):
     a = np.asarray(a)
@@ -39,6 +51,15 @@ def luma4x4(Y):
     Y = _plane(Y, "Y")
     Yres, Ypred, modes = any_context(*Y.shape).intra_luma(Y, 4)
     return Yres, Ypred, modes
+
+
+def transform4x4(Yres):
+    """The commented-out block of intraframe.py:352-358: every 4x4 block of the residual
+    plane becomes np.round(DCTTransform @ block @ DCTTransform.T).  Returns a new plane."""
+    Yres = np.asarray(Yres, dtype=np.float64)
+    if Yres.ndim != 2:
+        raise TypeError("Yres must be a 2-D plane")
+    return any_context(*Yres.shape).intra_transform4x4(Yres)
 
 
 def luma16x16(Y):

@@ -262,4 +262,47 @@ __global__ __launch_bounds__(64) void k_intra_chroma8(const uint8_t *__restrict_
     }
 }
 
+// --------------------------------------------------------------------------
+// k_intra_transform4: the 4x4 integer core transform the reference keeps
+// commented out behind its intra prediction (intraframe.py:14-17, :352-358):
+//   out = np.round(C . X . C^T) per 4x4 block of the residual plane,
+//   C = [[1,1,1,1],[2,1,-1,-2],[1,-1,-1,1],[1,-2,2,-1]].
+// No running upstream code pins it; for the integer-valued residuals the
+// intra predictors produce every order of evaluation is exact.  Thread = one
+// 4x4 block, rows as 32-byte loads; products left to right, np.round = rint.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_intra_transform4(const double *__restrict__ X, int H, int W,
+                                                          double *__restrict__ out) {
+    const int nbx = W >> 2, nb = nbx * (H >> 2);
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const int by = b / nbx, bx = b - by * nbx;
+    const size_t o = (size_t)(4 * by) * W + (size_t)(4 * bx);
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double x[4][4], t[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const d2 a = *(const d2 *)(X + o + (size_t)r * W), c = *(const d2 *)(X + o + (size_t)r * W + 2);
+        x[r][0] = a.x; x[r][1] = a.y; x[r][2] = c.x; x[r][3] = c.y;
+    }
+    constexpr double C[4][4] = {{1, 1, 1, 1}, {2, 1, -1, -2}, {1, -1, -1, 1}, {1, -2, 2, -1}};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            t[i][j] = ((C[i][0] * x[0][j] + C[i][1] * x[1][j]) + C[i][2] * x[2][j]) + C[i][3] * x[3][j];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double r[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            r[j] = __builtin_rint(((t[i][0] * C[j][0] + t[i][1] * C[j][1]) + t[i][2] * C[j][2]) +
+                                  t[i][3] * C[j][3]);
+        d2 a, c;
+        a.x = r[0]; a.y = r[1]; c.x = r[2]; c.y = r[3];
+        *(d2 *)(out + o + (size_t)i * W) = a;
+        *(d2 *)(out + o + (size_t)i * W + 2) = c;
+    }
+}
+
 }  // namespace vcs

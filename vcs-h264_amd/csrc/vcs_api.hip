@@ -1026,6 +1026,26 @@ int vcs_intra_chroma8x8(vcs_ctx *c, const uint8_t *Cr, const uint8_t *Cb, double
     return VCS_OK;
 }
 
+int vcs_intra_transform4x4(vcs_ctx *c, const double *res, double *out) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!res || !out) return fail(c, VCS_E_ARG, "null pointer");
+    const int H = c->g.H, W = c->g.W;
+    if (H % 4 || W % 4) return fail(c, VCS_E_ARG, "intra 4x4 transform needs multiples of 4");
+    if ((rc = ensure_intra(c))) return rc;
+    const size_t hw = (size_t)H * W, nb = hw / 16;
+    double *din = c->d_intra, *dout = c->d_intra + hw;
+    HIP_TRY(c, hipMemcpyAsync(din, res, hw * 8, hipMemcpyHostToDevice, c->stream));
+    EvPair ev;
+    if ((rc = t_begin(c, VCS_T_AUX, &ev))) return rc;
+    hipLaunchKernelGGL(k_intra_transform4, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream,
+                       din, H, W, dout);
+    if ((rc = t_end(c, &ev))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, dout, hw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
 int vcs_stream_wait(vcs_ctx *c, void *foreign_stream) {
     int rc = use(c);
     if (rc) return rc;

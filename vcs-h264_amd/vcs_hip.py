@@ -63,6 +63,7 @@ SIGNATURES = {
     "vcs_intra_luma4x4": (ctypes.c_int, [_c_ctx, _u8p, _f64p, _f64p, _f64p]),
     "vcs_intra_luma16x16": (ctypes.c_int, [_c_ctx, _u8p, _f64p, _f64p, _f64p]),
     "vcs_intra_chroma8x8": (ctypes.c_int, [_c_ctx, _u8p, _u8p, _f64p, _f64p, _f64p, _f64p, _f64p]),
+    "vcs_intra_transform4x4": (ctypes.c_int, [_c_ctx, _f64p, _f64p]),
     "vcs_stream_wait": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_signal": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_handle": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_void_p)]),
@@ -358,6 +359,16 @@ class Context:
                                                *[o.ctypes.data_as(_f64p) for o in outs],
                                                modes.ctypes.data_as(_f64p)))
         return outs[0], outs[1], outs[2], outs[3], modes
+
+    def intra_transform4x4(self, res):
+        """np.round(C . X . C^T) per 4x4 block of a float64 (H, W) plane (intraframe.py:352-358)."""
+        res = np.ascontiguousarray(res, dtype=np.float64)
+        if res.shape != (self.H, self.W):
+            raise ValueError("plane must have shape (%d, %d)" % (self.H, self.W))
+        out = np.zeros_like(res)
+        self._ck(self._lib.vcs_intra_transform4x4(self._h, res.ctypes.data_as(_f64p),
+                                                  out.ctypes.data_as(_f64p)))
+        return out
 
     # -- GOP path -----------------------------------------------------------
     def gop_reserve(self, n_slots, with_decode=False):
