@@ -596,6 +596,13 @@ def test_resident_planes_dropin(vh, capsys):
         if fr.t != "P":
             continue
         assert isinstance(fr.r, vh.ResidentPlanes) and fr.r._host is None  # nothing downloaded
+        # Frame.mv / Frame.c: list-like views (frame.RowList) that read like upstream's lists
+        want_mv = g["dct_mv_%d" % n]
+        assert not isinstance(fr.mv, list) and len(fr.mv) == len(want_mv) == len(fr.c)
+        assert fr.mv == want_mv.tolist() and fr.mv[3] == want_mv[3].tolist()
+        assert isinstance(fr.mv[0][0], int) and fr.mv[1:3] == want_mv[1:3].tolist()
+        assert [list(p) for p in fr.mv] == want_mv.tolist()
+        assert fr.c[1] == [8, 0] and fr.c.tolist()[W // 8] == [0, 8]
         assert np.array_equal(np.array(fr.mv), g["dct_mv_%d" % n])
         assert np.array_equal(dec._reconstruct_P_frame(fr, True), g["dct_full_%d" % n])
         assert fr.r._host is None                                         # ... still nothing

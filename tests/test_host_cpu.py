@@ -119,3 +119,28 @@ def test_synth_is_deterministic():
     assert np.array_equal(ref, ref2) and np.array_equal(fr[2:], fr2)
     r, c = synth_static(64, 64, seed=1, bs=16, frac=0.5)
     assert r.shape == c.shape == (64, 64, 3)
+
+
+def test_rowlist_reads_like_a_list_of_pairs():
+    """frame.RowList (Encoder(resident=True) stores Frame.mv / Frame.c in it): the accesses
+    the reference makes on those lists -- len, indexing, iteration, np.array -- and a few
+    more, without N Python lists behind it."""
+    import sys
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vcs-h264_amd",
+                     "InterframeCompression")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    from frame import RowList
+    a = np.array([[1, -2], [3, 4], [-5, 6], [7, 8]], np.int64)
+    v = RowList(a)
+    assert len(v) == 4 and v[2] == [-5, 6] and v[-1] == [7, 8] and v[1:3] == [[3, 4], [-5, 6]]
+    assert type(v[0][0]) is int and list(v) == a.tolist() and v.tolist() == a.tolist()
+    assert v == a.tolist() and v == RowList(a.copy()) and not (v == a[:3].tolist())
+    assert np.asarray(v) is a and np.array_equal(np.array(v, np.int16), a)
+    for (dx, dy), (x, y) in zip(v, RowList(a + 1)):   # decoder.py:62-65 style consumption
+        assert (x, y) == (dx + 1, dy + 1)
+    with pytest.raises(IndexError):
+        v[4]
+    with pytest.raises(ValueError):
+        RowList(np.zeros((3, 3)))

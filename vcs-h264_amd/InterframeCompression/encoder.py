@@ -12,7 +12,8 @@ blocks with the 8x8 DCT (the BASELINE workload).  `resident=True` (or the
 environment variable VCS_RESIDENT=1, so that an unchanged main.py can opt in)
 leaves the coefficient planes of Frame.r in HBM: Frame.r is then a list-like
 view that downloads on first access, and the drop-in Decoder decodes straight
-from HBM -- the 8x-frame-size planes never cross PCIe.
+from HBM -- the 8x-frame-size planes never cross PCIe; Frame.mv and Frame.c are
+then list-like views of integer arrays (frame.RowList) instead of N Python lists.
 """
 import os
 import math
@@ -20,7 +21,7 @@ import math
 import numpy as np
 
 from DCTcompressor import DCTCompressor
-from frame import Frame
+from frame import Frame, RowList
 from motion import MotionProcessor, _as_frame
 from _runtime import ensure_q, ensure_ref
 
@@ -87,5 +88,14 @@ class Encoder:
             r = planes if keep else [planes[0], planes[1], planes[2]]
         else:
             r = res
+        if self.resident:  # list-like views, no per-block Python objects (frame.RowList)
+            return Frame("P", motion_vectors=RowList(mv.astype(np.int64)), residuals=r,
+                         block_coords=RowList(self._coords(mp)), index=frame_num, ref_idx=ref_idx)
         return Frame("P", motion_vectors=mv.astype(np.int64).tolist(), residuals=r,
                      block_coords=mp._block_coords().tolist(), index=frame_num, ref_idx=ref_idx)
+
+    def _coords(self, mp):
+        c = getattr(self, "_coords_cache", None)
+        if c is None:
+            c = self._coords_cache = mp._block_coords()  # the same grid for every frame
+        return c
