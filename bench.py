@@ -93,6 +93,12 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
                      "--nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a
+    # version banner when the process group comes up), so file descriptor 1 is pointed at
+    # stderr for the whole run and the line goes to a private copy of the original stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     dist = torch = None
     use_dist = world > 1 or (args.force_dist and "RANK" in os.environ)
     if use_dist:
@@ -319,7 +325,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(H, W, bs, ref, frames)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ctx.close()
     if use_dist:
         dist.barrier()

@@ -37,24 +37,28 @@ __global__ __launch_bounds__(64) void k_shape(const uint8_t *img, double *planes
 int main() {
     const int H = 1080, W = 1920, n = 29;
     const size_t F = (size_t)H * W * 3;
-    uint8_t *img; double *planes;
-    hipMalloc(&img, F * n + 64); hipMalloc(&planes, F * n * 8);
+    uint8_t *img; double *planes, *planes2;
+    hipMalloc(&img, F * n + 64); hipMalloc(&planes, F * n * 8); hipMalloc(&planes2, F * n * 8);
     hipMemset(img, 7, F * n + 64);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const unsigned grid = (unsigned)((W / 64) * (H / 8) * n);
+    // alt = 1: consecutive launches write two different 1.44 GB regions in turn (what happens
+    // when alternate GOPs go to alternate slots) instead of rewriting the same one
+    for (int alt = 0; alt < 2; alt++)
     for (int nt = 0; nt < 2; nt++) {
         float best = 1e9f;
         for (int it = 0; it < 12; it++) {
+            double *dst = (alt && (it & 1)) ? planes2 : planes;
             hipEventRecord(a);
-            if (nt) hipLaunchKernelGGL(k_shape<true>, dim3(grid), dim3(64), 0, 0, img, planes, H, W, n);
-            else hipLaunchKernelGGL(k_shape<false>, dim3(grid), dim3(64), 0, 0, img, planes, H, W, n);
+            if (nt) hipLaunchKernelGGL(k_shape<true>, dim3(grid), dim3(64), 0, 0, img, dst, H, W, n);
+            else hipLaunchKernelGGL(k_shape<false>, dim3(grid), dim3(64), 0, 0, img, dst, H, W, n);
             hipEventRecord(b); hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
             if (it > 1 && ms < best) best = ms;
         }
         const double bytes = (double)F * n * 9;  // 1 read + 8 written per pixel byte
-        printf("shape kernel, %s stores: %.3f ms  %.0f GB/s (reads + writes)\n", nt ? "non-temporal" : "plain",
-               best, bytes / best / 1e6);
+        printf("shape kernel, %s stores, %s: %.3f ms  %.0f GB/s (reads + writes)\n",
+               nt ? "non-temporal" : "plain", alt ? "two regions in turn" : "same region", best, bytes / best / 1e6);
     }
     return 0;
 }
