@@ -387,14 +387,18 @@ inline int launch_me_roll(const Geom &g, hipStream_t stream, int cus, const uint
     const int seg = me16r_seg_len(g.nby);
     const long long units = (long long)n * ((g.nby + seg - 1) / seg) * g.nbx;
     dim3 gd(me16_grid(cus, units)), block(64);
+    hipLaunchKernelGGL(k_me16r, gd, block, 0, stream, ref, curs, stride, g, n, seg, sums,
+                       mv, ns, cost);
+    return 0;
+}
+// Must be the last kernel dispatched before launch_me_roll (see k_me16r_primer); also
+// zeroes the n per-frame static-block counters.
+inline void launch_me_roll_primer(hipStream_t stream, int cus, uint32_t *ns, int n) {
     static const bool primer = [] {
         const char *e = getenv("VCS_ME16_PRIMER");  // 0 = a single workgroup (A/B measurements)
         return !(e && e[0] == '0');
     }();
     hipLaunchKernelGGL(k_me16r_primer, dim3(primer ? cus : 1), dim3(64), 0, stream, ns, n);
-    hipLaunchKernelGGL(k_me16r, gd, block, 0, stream, ref, curs, stride, g, n, seg, sums,
-                       mv, ns, cost);
-    return 0;
 }
 
 }  // namespace vcs

@@ -203,25 +203,25 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     // the per-frame static-block counters start at zero; the rolling kernel's primer does it
     const bool roll = c->me_fast_ok && !force_generic && me16r_worthwhile(c->g, c->cus, n);
     if (!roll) HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
+    // per-reference sum(r) table, once per reference frame (all P frames of a GOP share it);
+    // outside the VCS_T_ME bracket, which times the search kernel (with its 5 us primer, which
+    // has to be the dispatch right before it)
+    if (!c->sums_valid && !force_generic && (c->me_fast_ok || c->me_fast8_ok)) {
+        if (c->me_fast_ok) launch_me_fast_sums(c->g, c->stream, c->cus, ref, c->d_sums);
+        else launch_me_fast8_sums(c->g, c->stream, c->cus, ref, c->d_sums);
+        HIP_TRY(c, hipGetLastError());
+        c->sums_valid = true;
+    }
     EvPair ev;
     int rc = t_begin(c, VCS_T_ME, &ev);
     if (rc) return rc;
+    if (roll) launch_me_roll_primer(c->stream, c->cus, ns, n);
     if (c->me_fast_ok && !force_generic) {
-        if (!c->sums_valid) {  // once per reference frame (all P frames of a GOP share it)
-            launch_me_fast_sums(c->g, c->stream, c->cus, ref, c->d_sums);
-            HIP_TRY(c, hipGetLastError());
-            c->sums_valid = true;
-        }
         rc = roll
                  ? launch_me_roll(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost)
                  : launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
     } else if (c->me_fast8_ok && !force_generic) {
-        if (!c->sums_valid) {
-            launch_me_fast8_sums(c->g, c->stream, c->cus, ref, c->d_sums);
-            HIP_TRY(c, hipGetLastError());
-            c->sums_valid = true;
-        }
         rc = launch_me_fast8(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
     } else {
