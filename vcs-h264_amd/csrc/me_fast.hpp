@@ -42,6 +42,8 @@
 
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "vcs_common.hpp"
 
 namespace vcs {
@@ -471,7 +473,8 @@ inline int launch_me_fast_sums(const Geom &g, hipStream_t stream, int cus, const
 // are indexed frame-major, i.e. by work item.  `sums` must hold ref's table.
 inline int launch_me_fast(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                           const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
-                          uint32_t *ns, unsigned long long *cost) {
+                          uint32_t *ns, unsigned long long *cost, hipEvent_t ev_start = nullptr,
+                          hipEvent_t ev_stop = nullptr) {
     const long long total = (long long)g.N * n;
     if (total > 0x7FFFFFFF) return -1;
     dim3 gd(me16_grid(cus, total)), block(64);
@@ -481,8 +484,8 @@ inline int launch_me_fast(const Geom &g, hipStream_t stream, int cus, const uint
     hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * gd.x, stream);
     cost = dbg;
 #endif
-    hipLaunchKernelGGL((k_me16<18>), gd, block, 0, stream, ref, curs, stride, g,
-                       (int)total, sums, mv, ns, cost);
+    hipExtLaunchKernelGGL((k_me16<18>), gd, block, 0, stream, ev_start, ev_stop, 0, ref, curs, stride, g,
+                          (int)total, sums, mv, ns, cost);
 #ifdef VCS_ME16_STAMPS
     {
         static int calls = 0;

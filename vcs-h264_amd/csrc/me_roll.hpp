@@ -13,6 +13,8 @@
 // k_me16 is unaffected (64 rows * 18 slots = 0 mod 16).
 // Results are identical to k_me16 / k_me_generic.
 #pragma once
+#include <hip/hip_ext.h>
+
 #include "me_fast.hpp"
 
 namespace vcs {
@@ -382,13 +384,15 @@ inline bool me16r_worthwhile(const Geom &g, int cus, int n) {
 }
 inline int launch_me_roll(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                           const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
-                          uint32_t *ns, unsigned long long *cost) {
+                          uint32_t *ns, unsigned long long *cost, hipEvent_t ev_start = nullptr,
+                          hipEvent_t ev_stop = nullptr) {
     if ((long long)g.N * n > 0x7FFFFFFF) return -1;
     const int seg = me16r_seg_len(g.nby);
     const long long units = (long long)n * ((g.nby + seg - 1) / seg) * g.nbx;
     dim3 gd(me16_grid(cus, units)), block(64);
-    hipLaunchKernelGGL(k_me16r, gd, block, 0, stream, ref, curs, stride, g, n, seg, sums,
-                       mv, ns, cost);
+    // the events (optional) take this dispatch's own start / end timestamps
+    hipExtLaunchKernelGGL(k_me16r, gd, block, 0, stream, ev_start, ev_stop, 0, ref, curs, stride, g, n,
+                          seg, sums, mv, ns, cost);
     return 0;
 }
 // Must be the last kernel dispatched before launch_me_roll (see k_me16r_primer); also

@@ -1,6 +1,7 @@
 // vcs_api.hip -- the C ABI of libvcs_hip.so (include/vcs_hip.h): contexts, HBM
 // buffers, launch chains, timing.  Host C++ + HIP runtime only; no PyTorch.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -27,8 +28,9 @@ namespace {
 thread_local std::string g_err;
 
 struct EvPair {
-    hipEvent_t a, b;
-    int slot;
+    hipEvent_t a = nullptr, b = nullptr;
+    int slot = 0;
+    bool attached = false;  // events ride on one kernel's dispatch packet (hipExtLaunchKernelGGL)
 };
 
 }  // namespace
@@ -161,8 +163,15 @@ void refresh_q(vcs_ctx *c) {
 }
 
 // ---- timing brackets -----------------------------------------------------
-int t_begin(vcs_ctx *c, int slot, EvPair *ev) {
+// Two forms.  Recorded: hipEventRecord before and after whatever is launched in between
+// (each record is a packet of its own on the queue, ~5 us).  Attached (attach = true): the
+// caller passes ev->a / ev->b to hipExtLaunchKernelGGL, which takes the start and end
+// timestamps of that one kernel's dispatch packet -- no extra packets, and exactly the
+// kernel's duration.  With timing off both are no-ops and ev->a / ev->b stay null.
+int t_begin(vcs_ctx *c, int slot, EvPair *ev, bool attach = false) {
     c->launches[slot]++;
+    ev->a = ev->b = nullptr;
+    ev->attached = attach;
     if (!c->timing) return VCS_OK;
     if (!c->pool.empty()) {
         *ev = c->pool.back();
@@ -172,13 +181,14 @@ int t_begin(vcs_ctx *c, int slot, EvPair *ev) {
         HIP_TRY(c, hipEventCreate(&ev->b));
     }
     ev->slot = slot;
-    HIP_TRY(c, hipEventRecord(ev->a, c->stream));
+    ev->attached = attach;  // (the pooled pair carried its previous use's flag)
+    if (!attach) HIP_TRY(c, hipEventRecord(ev->a, c->stream));
     return VCS_OK;
 }
 int t_end(vcs_ctx *c, EvPair *ev) {
     HIP_TRY(c, hipGetLastError());
-    if (!c->timing) return VCS_OK;
-    HIP_TRY(c, hipEventRecord(ev->b, c->stream));
+    if (!c->timing || !ev->a) return VCS_OK;
+    if (!ev->attached) HIP_TRY(c, hipEventRecord(ev->b, c->stream));
     c->pending.push_back(*ev);
     return VCS_OK;
 }
@@ -204,22 +214,23 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     const bool roll = c->me_fast_ok && !force_generic && me16r_worthwhile(c->g, c->cus, n);
     if (!roll) HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
     // per-reference sum(r) table, once per reference frame (all P frames of a GOP share it);
-    // outside the VCS_T_ME bracket, which times the search kernel (with its 5 us primer, which
-    // has to be the dispatch right before it)
+    // not part of VCS_T_ME, which times the search kernel alone
     if (!c->sums_valid && !force_generic && (c->me_fast_ok || c->me_fast8_ok)) {
         if (c->me_fast_ok) launch_me_fast_sums(c->g, c->stream, c->cus, ref, c->d_sums);
         else launch_me_fast8_sums(c->g, c->stream, c->cus, ref, c->d_sums);
         HIP_TRY(c, hipGetLastError());
         c->sums_valid = true;
     }
+    const bool fast16 = c->me_fast_ok && !force_generic;
     EvPair ev;
-    int rc = t_begin(c, VCS_T_ME, &ev);
+    int rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/fast16);  // k_me16r / k_me16: the kernel alone
     if (rc) return rc;
     if (roll) launch_me_roll_primer(c->stream, c->cus, ns, n);
-    if (c->me_fast_ok && !force_generic) {
-        rc = roll
-                 ? launch_me_roll(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost)
-                 : launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
+    if (fast16) {
+        rc = roll ? launch_me_roll(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost,
+                                   ev.a, ev.b)
+                  : launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost,
+                                   ev.a, ev.b);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
     } else if (c->me_fast8_ok && !force_generic) {
         rc = launch_me_fast8(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
@@ -254,11 +265,11 @@ int launch_fdct(vcs_ctx *c, int tslot, const uint8_t *imgs, size_t stride, const
     const int map = tail_map();
     dim3 grid(tail_grid(g, n, map)), block(64);
     EvPair ev;
-    int rc = t_begin(c, tslot, &ev);
+    int rc = t_begin(c, tslot, &ev, /*attach=*/true);
     if (rc) return rc;
-#define VCS_FDCT(CM, FD, T)                                                                  \
-    hipLaunchKernelGGL((k_fdct<MODE, CM, FD>), grid, block, 0, c->stream, imgs, stride, ref, mv, \
-                       g, c->d_DQ, (T *)planes, pstride_elems, n, map)
+#define VCS_FDCT(CM, FD, T)                                                                      \
+    hipExtLaunchKernelGGL((k_fdct<MODE, CM, FD>), grid, block, 0, c->stream, ev.a, ev.b, 0, imgs, \
+                          stride, ref, mv, g, c->d_DQ, (T *)planes, pstride_elems, n, map)
     switch (c->coeff_mode) {
         case VCS_COEFF_F64:
             if (c->fastdiv) VCS_FDCT(0, true, double); else VCS_FDCT(0, false, double);
@@ -282,21 +293,23 @@ int launch_idct(vcs_ctx *c, int tslot, const void *planes, size_t pstride_elems,
     const int map = tail_map();
     dim3 grid(tail_grid(g, n, map)), block(64);
     EvPair ev;
-    int rc = t_begin(c, tslot, &ev);
+    int rc = t_begin(c, tslot, &ev, /*attach=*/true);
     if (rc) return rc;
     switch (c->coeff_mode) {
         case VCS_COEFF_F64:
-            hipLaunchKernelGGL((k_idct<MODE, 0>), grid, block, 0, c->stream, (const double *)planes,
-                               pstride_elems, ref, mv, g, c->d_DQ, outs, ostride, n, map);
+            hipExtLaunchKernelGGL((k_idct<MODE, 0>), grid, block, 0, c->stream, ev.a, ev.b, 0,
+                                  (const double *)planes, pstride_elems, ref, mv, g, c->d_DQ, outs,
+                                  ostride, n, map);
             break;
         case VCS_COEFF_F32:
-            hipLaunchKernelGGL((k_idct<MODE, 1>), grid, block, 0, c->stream, (const float *)planes,
-                               pstride_elems, ref, mv, g, c->d_DQ, outs, ostride, n, map);
+            hipExtLaunchKernelGGL((k_idct<MODE, 1>), grid, block, 0, c->stream, ev.a, ev.b, 0,
+                                  (const float *)planes, pstride_elems, ref, mv, g, c->d_DQ, outs,
+                                  ostride, n, map);
             break;
         default:
-            hipLaunchKernelGGL((k_idct<MODE, 2>), grid, block, 0, c->stream,
-                               (const int16_t *)planes, pstride_elems, ref, mv, g, c->d_DQ, outs,
-                               ostride, n, map);
+            hipExtLaunchKernelGGL((k_idct<MODE, 2>), grid, block, 0, c->stream, ev.a, ev.b, 0,
+                                  (const int16_t *)planes, pstride_elems, ref, mv, g, c->d_DQ, outs,
+                                  ostride, n, map);
             break;
     }
     return t_end(c, &ev);
