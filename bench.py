@@ -78,6 +78,14 @@ def main():
     ap.add_argument("--same-ref", action="store_true",
                     help="diagnostic: do not declare a new I frame per step (the per-reference sum "
                          "table is then built once, outside the timed region)")
+    ap.add_argument("--slot-sets", type=int, default=1,
+                    help="diagnostic (single GPU): K resident copies of the GOP in K sets of slots, "
+                         "encoded in turn, so that consecutive steps neither read the same input "
+                         "frames nor write the same output planes (default 1: one resident GOP)")
+    ap.add_argument("--rotate-sets", type=int, default=3,
+                    help="single GPU: after the main measurement, repeat it rotating through this many "
+                         "resident copies of the GOP (inputs no longer in the 256 MB Infinity Cache "
+                         "from the previous step) and report it as `rotating_inputs`; 0 = skip")
     ap.add_argument("--serial-comm", action="store_true",
                     help="multi-GPU: broadcast -> kernels -> all-gather strictly in sequence "
                          "instead of overlapping the collectives with the neighbouring GOPs' kernels")
@@ -87,6 +95,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.steps = max(1, args.steps)
+    args.warmup = max(0, args.warmup)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -116,8 +126,12 @@ def main():
     # this rank's slice of the (long) GOP; synthetic, deterministic
     ref, frames = synth_gop(H, W, n, seed=1234, first=1 + rank * n)
     overlap = use_dist and not args.serial_comm
-    ctx.gop_reserve(n, with_decode=args.with_decode)
-    ctx.gop_upload(0, frames)
+    sets = max(1, args.slot_sets) if not use_dist else 1
+    rot = max(0, args.rotate_sets) if (not use_dist and sets == 1) else 0
+    ctx.gop_reserve(max(sets, rot) * n, with_decode=args.with_decode)
+    for k in range(max(sets, rot)):
+        ctx.gop_upload(k * n, frames)
+    set_state = {"k": 0}
     if use_dist:
         if rank == 0:
             ctx.set_ref(ref)        # the I frame enters HBM on rank 0 only
@@ -195,7 +209,9 @@ def main():
         # redone inside the timed region, once per GOP as in a real encode
         if not args.same_ref:
             ctx.ref_written()
-        ctx.gop_encode(0, n)                         # ME kernel + fused tail kernel
+        if sets > 1:
+            set_state["k"] = (set_state["k"] + 1) % sets
+        ctx.gop_encode(set_state["k"] * n, n)        # ME kernel + fused tail kernel
         if use_dist:
             ctx.stream_signal(ts)                    # collectives wait for the kernels, GPU-side
             dist.all_gather_into_tensor(t_all, t_mv)  # motion-vector collection
@@ -273,6 +289,7 @@ def main():
                                                                   round(bs / 3)),
                        "frames_per_step_per_gpu": n, "macroblocks_per_frame": N,
                        "searched_block_fraction": round(searched, 4),
+                       "resident_gop_sets_encoded_in_turn": sets,
                        "parallelism": "P frames sharded over %d GPU(s)" % world,
                        "collectives": ("none" if not use_dist else
                                        "RCCL broadcast (I frame) + all-gather (vectors) per GOP, " +
@@ -307,6 +324,32 @@ def main():
                                        "fill_write_only": round(ctx.measure_fill_bw(1 << 28, 5), 0)}
         except vcs_hip.VcsError:
             pass
+        if rot > 1:
+            # The main loop re-encodes ONE resident GOP: its 29 input frames (180 MB) are read
+            # again every step and stay in the 256 MB Infinity Cache (the planes are written
+            # with non-temporal stores and do not evict them).  Same measurement, rotating
+            # through `rot` resident copies so that a step's inputs were last touched rot
+            # steps ago: what a stream of GOPs costs when nothing comes from that cache.
+            def rstep(k):
+                ctx.ref_written()
+                ctx.gop_encode((k % rot) * n, n)
+            for k in range(rot):
+                rstep(k)
+            ctx.sync()
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                rstep(k)
+            ctx.sync()
+            dtr = time.perf_counter() - t1
+            msr, lr = ctx.timing()
+            ctx.timing_enable(False)
+            out["rotating_inputs"] = {
+                "resident_gop_sets": rot, "value": round(n * N * args.steps / dtr / 1e3, 2),
+                "unit": "macroblocks/ms", "ms_per_step": round(dtr / args.steps * 1e3, 4),
+                "kernel_ms_per_step": {"me": round(msr[vcs_hip.T_ME] / args.steps, 4),
+                                       "enc_tail": round(msr[vcs_hip.T_ENC_TAIL] / args.steps, 4)}}
         if args.with_decode:
             # second line of SURVEY 8d: dequantise + IDCT + colour + MC-add over the same GOP
             ctx.timing_enable(True)
