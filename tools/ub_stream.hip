@@ -40,6 +40,7 @@ int main() {
     uint8_t *img, *img2, *img3; double *planes, *planes2;
     hipMalloc(&img, F * n + 64); hipMalloc(&img2, F * n + 64); hipMalloc(&img3, F * n + 64);
     hipMemset(img2, 9, F * n + 64); hipMemset(img3, 11, F * n + 64); hipMalloc(&planes, F * n * 8); hipMalloc(&planes2, F * n * 8);
+    double *planes3; hipMalloc(&planes3, F * n * 8);
     hipMemset(img, 7, F * n + 64);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const unsigned grid = (unsigned)((W / 64) * (H / 8) * n);
@@ -47,12 +48,14 @@ int main() {
     // when alternate GOPs go to alternate slots) instead of rewriting the same one;
     // alt = 2: they read three different 180 MB inputs in turn instead (540 MB: more than the
     // 256 MB Infinity Cache holds), writing the same region
-    for (int alt = 0; alt < 3; alt++)
+    // alt = 3: both (three inputs, three output regions)
+    for (int alt = 0; alt < 4; alt++)
     for (int nt = 0; nt < 2; nt++) {
         float best = 1e9f;
         for (int it = 0; it < 12; it++) {
             double *dst = (alt == 1 && (it & 1)) ? planes2 : planes;
-            const uint8_t *src = alt == 2 ? (it % 3 == 0 ? img : it % 3 == 1 ? img2 : img3) : img;
+            if (alt == 3) dst = it % 3 == 0 ? planes : it % 3 == 1 ? planes2 : planes3;
+            const uint8_t *src = alt >= 2 ? (it % 3 == 0 ? img : it % 3 == 1 ? img2 : img3) : img;
             hipEventRecord(a);
             if (nt) hipLaunchKernelGGL(k_shape<true>, dim3(grid), dim3(64), 0, 0, src, dst, H, W, n);
             else hipLaunchKernelGGL(k_shape<false>, dim3(grid), dim3(64), 0, 0, src, dst, H, W, n);
@@ -62,7 +65,7 @@ int main() {
         }
         const double bytes = (double)F * n * 9;  // 1 read + 8 written per pixel byte
         printf("shape kernel, %s stores, %s: %.3f ms  %.0f GB/s (reads + writes)\n",
-               nt ? "non-temporal" : "plain", alt == 1 ? "two output regions in turn" : alt == 2 ? "three inputs in turn" : "same input and region", best, bytes / best / 1e6);
+               nt ? "non-temporal" : "plain", alt == 1 ? "two output regions in turn" : alt == 2 ? "three inputs in turn" : alt == 3 ? "three inputs and three output regions in turn" : "same input and region", best, bytes / best / 1e6);
     }
     return 0;
 }
