@@ -63,6 +63,12 @@ typedef struct vcs_ctx vcs_ctx;
 /* ---- library / device -------------------------------------------------- */
 int vcs_abi_version(void);
 int vcs_device_count(int *n);
+/* Page-locked host memory for frames and planes (hipHostMalloc): buffers handed to the
+ * entry points below are copied by DMA at PCIe rate when they live in such memory and
+ * through the runtime's staging path otherwise (a 1080p frame: 0.12 vs 0.5 ms).  The
+ * frame feeder of SURVEY 8f N3: the producer (video decoder) writes into these.        */
+int vcs_host_alloc(size_t bytes, void **ptr);
+int vcs_host_free(void *ptr);
 /* Message of the last failure on `ctx` (or, with ctx == NULL, of the last
  * failed vcs_ctx_create / vcs_device_count on this thread).                 */
 const char *vcs_last_error(const vcs_ctx *ctx);

@@ -197,6 +197,32 @@ def test_ref_swap_alternates_two_resident_references(vh, oracle):
             assert np.array_equal(c.me(cur)[0], want)
 
 
+def test_pinned_host_buffers(vh, oracle):
+    """vcs_host_alloc (frame feeder): frames produced into page-locked memory go
+    through the same entry points with the same results; the memory is released with the array."""
+    import gc
+    from synth import synth_v1
+    ref, cur = synth_v1(96, 128, seed=31)
+    pref, pcur = vh.pinned_empty(ref.shape), vh.pinned_empty(cur.shape)
+    assert pref.flags["C_CONTIGUOUS"] and pref.dtype == np.uint8 and pref.shape == ref.shape
+    pref[...] = ref
+    pcur[...] = cur
+    planes_out = vh.pinned_empty((3, 96, 128), np.float64)
+    with vh.Context(96, 128, 16) as c:
+        c.set_ref(pref)
+        mv, planes, _, ns = c.encode_p(pcur)
+        omv, oplanes, ons = oracle.encode_p(cur, ref, 16)
+        assert np.array_equal(mv, omv) and ns == ons and np.array_equal(planes, oplanes)
+        planes_out[...] = planes
+        assert np.array_equal(c.decode_p(mv, planes_out), oracle.decode_p(omv, oplanes, ref, 16))
+    view = pcur[10:20]
+    del pref, pcur, planes_out
+    gc.collect()
+    assert view.sum() == cur[10:20].sum()      # a view keeps the allocation alive
+    with pytest.raises(ValueError):
+        vh.pinned_empty((0, 4))
+
+
 def _psnr(a, b):
     mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
     return float("inf") if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)

@@ -19,6 +19,18 @@ with vcs_hip.Context(H, W, 16) as c:
             c.encode_p(frames[k])
         dt = (time.perf_counter() - t0) / n
         print("vcs_encode_p host buffers, %s planes: %.2f ms/frame = %.0f macroblocks/ms" % (name, dt * 1e3, N / dt / 1e3))
+    # the same with the frames in page-locked memory (vcs_hip.pinned_empty): DMA at PCIe rate
+    pinned = [vcs_hip.pinned_empty(frames[0].shape) for _ in range(n)]
+    for k in range(n):
+        pinned[k][...] = frames[k]
+    c.set_params(coeff_mode=2)
+    c.encode_p(pinned[0])
+    t0 = time.perf_counter()
+    for k in range(n):
+        c.encode_p(pinned[k])
+    dt = (time.perf_counter() - t0) / n
+    print("vcs_encode_p, frames in pinned host memory, int16 planes: %.2f ms/frame = %.0f macroblocks/ms" % (dt * 1e3, N / dt / 1e3))
+    c.set_params(coeff_mode=0)
 import encoder as E
 enc = E.Encoder(pattern=["I"] + ["P"] * 29, shape=[H, W], block_size=16, with_DCT=True, dct_block_size=8)
 with contextlib.redirect_stdout(io.StringIO()):
@@ -44,3 +56,12 @@ with contextlib.redirect_stdout(io.StringIO()):
         dec._reconstruct_P_frame(fr, True)
     dd = (time.perf_counter() - t0) / n
 print("drop-in Encoder(resident=True).encode_frame: %.2f ms/frame = %.0f macroblocks/ms; Decoder from HBM: %.2f ms/frame" % (dt * 1e3, N / dt / 1e3, dd * 1e3))
+enc = E.Encoder(pattern=["I"] + ["P"] * 29, shape=[H, W], block_size=16, with_DCT=True, dct_block_size=8, resident=True)
+pref = vcs_hip.pinned_empty(ref.shape); pref[...] = ref
+with contextlib.redirect_stdout(io.StringIO()):
+    enc.encode_frame(pref, 0); enc.encode_frame(pinned[0], 1)
+    t0 = time.perf_counter()
+    for k in range(n):
+        enc.encode_frame(pinned[k], k + 2)
+    dt = (time.perf_counter() - t0) / n
+print("drop-in Encoder(resident=True).encode_frame, frames in pinned host memory: %.2f ms/frame = %.0f macroblocks/ms" % (dt * 1e3, N / dt / 1e3))

@@ -392,6 +392,25 @@ extern "C" {
 
 int vcs_abi_version(void) { return VCS_ABI_VERSION; }
 
+int vcs_host_alloc(size_t bytes, void **ptr) {
+    if (!ptr || bytes == 0) return fail(nullptr, VCS_E_ARG, "null pointer or zero size");
+    *ptr = nullptr;
+    hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *ptr = nullptr;
+        return fail(nullptr, e == hipErrorOutOfMemory ? VCS_E_NOMEM : VCS_E_HIP, "hipHostMalloc(%zu): %s",
+                    bytes, hipGetErrorString(e));
+    }
+    return VCS_OK;
+}
+
+int vcs_host_free(void *ptr) {
+    if (!ptr) return VCS_OK;
+    hipError_t e = hipHostFree(ptr);
+    if (e != hipSuccess) return fail(nullptr, VCS_E_HIP, "hipHostFree: %s", hipGetErrorString(e));
+    return VCS_OK;
+}
+
 int vcs_device_count(int *n) {
     if (!n) return fail(nullptr, VCS_E_ARG, "null pointer");
     int k = 0;

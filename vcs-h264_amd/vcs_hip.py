@@ -30,6 +30,8 @@ _vp = ctypes.c_void_p
 SIGNATURES = {
     "vcs_abi_version": (ctypes.c_int, []),
     "vcs_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "vcs_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "vcs_host_free": (ctypes.c_int, [ctypes.c_void_p]),
     "vcs_last_error": (ctypes.c_char_p, [_c_ctx]),
     "vcs_ctx_create": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.POINTER(_c_ctx)]),
     "vcs_ctx_destroy": (ctypes.c_int, [_c_ctx]),
@@ -108,6 +110,26 @@ def device_count():
     n = ctypes.c_int(0)
     rc = load().vcs_device_count(ctypes.byref(n))
     return n.value if rc == 0 else 0
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """An uninitialised NumPy array in page-locked host memory (vcs_host_alloc): frames the
+    producer writes here, and planes downloaded here, cross PCIe by DMA instead of through
+    the runtime's staging copies.  Freed when the array (and every view of it) is gone."""
+    import weakref
+    dtype = np.dtype(dtype)
+    shape = (shape,) if isinstance(shape, int) else tuple(int(x) for x in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes <= 0:
+        raise ValueError("empty shape")
+    lib = load()
+    p = ctypes.c_void_p()
+    rc = lib.vcs_host_alloc(ctypes.c_size_t(nbytes), ctypes.byref(p))
+    if rc:
+        raise VcsError(rc, (lib.vcs_last_error(None) or b"").decode())
+    buf = (ctypes.c_uint8 * nbytes).from_address(p.value)
+    weakref.finalize(buf, lib.vcs_host_free, ctypes.c_void_p(p.value))  # the array keeps `buf` alive
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
 def make_q(qf=50.0):
