@@ -83,9 +83,14 @@ const char *vcs_last_error(const vcs_ctx *ctx);
 int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **out);
 int vcs_ctx_destroy(vcs_ctx *ctx);
 
-/* Override the search / quantiser parameters.  win, step <= 0 and Q3x64 ==
- * NULL keep the current value.  Q3x64: 3 x 8 x 8 float64, row-major, every
- * entry finite and != 0 (the `Q` list of DCTcompressor.py:36-38).           */
+/* Override the search / quantiser parameters.  win, step <= 0, sim_thresh ==
+ * VCS_KEEP_THRESH, Q3x64 == NULL and coeff_mode == VCS_KEEP keep the current
+ * value (so a caller that only pushes Q never resets motion.py:8's threshold).
+ * sim_thresh < 0 (other than the sentinel): no block is ever static.
+ * Q3x64: 3 x 8 x 8 float64, row-major, every entry finite and != 0 (the `Q`
+ * list of DCTcompressor.py:36-38).                                          */
+#define VCS_KEEP (-1)
+#define VCS_KEEP_THRESH INT64_MIN
 int vcs_set_params(vcs_ctx *ctx, int win, int step, int64_t sim_thresh,
                    const double *Q3x64, int coeff_mode);
 /* Fills Q3x64 by the reference's QF rule (DCTcompressor.py:29-38).          */

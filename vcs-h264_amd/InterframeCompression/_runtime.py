@@ -39,19 +39,35 @@ def release_contexts():
     _CONTEXTS.clear()
 
 
+try:  # fast non-cryptographic hash (several GB/s); zlib.crc32 otherwise
+    from xxhash import xxh3_64_intdigest as _hash_bytes
+except ImportError:  # pragma: no cover
+    from zlib import crc32 as _hash_bytes
+
+
 def _token(frame):
-    """Identity + sparse checksum of a frame: lets the resident I frame be
-    reused across the P frames of a GOP without re-hashing 6-25 MB per call."""
-    flat = frame.reshape(-1)
-    return (id(frame), frame.ctypes.data, frame.shape, int(flat[::61].sum(dtype=np.uint64)))
+    """Identity + a hash of EVERY byte of a frame.  The reference aliases the
+    caller's I-frame array (encoder.py:42), so an in-place edit of that buffer must
+    reach the P frames encoded afterwards: the resident copy in HBM is only reused
+    while the whole buffer still hashes the same (0.3-0.6 ms per 1080p frame; the
+    frame feeder, which owns its reference, uses an explicit generation instead)."""
+    return (frame.shape, _hash_bytes(memoryview(frame).cast("B")))
 
 
-def ensure_ref(ctx, ref_frame):
+def ensure_ref(ctx, ref_frame, generation=None):
+    """Make `ref_frame` the context's resident reference.  `generation` (any hashable,
+    not None): the caller vouches that the same generation means the same bytes --
+    no hashing (Encoder(resident=True) keys it on the I frame's index and exposes
+    invalidate_ref() for callers that edit the I frame in place)."""
     ref = np.ascontiguousarray(ref_frame)
-    tok = _token(ref)
+    tok = ("gen", generation, ref.shape) if generation is not None else _token(ref)
     if ctx._ref_token != tok:
         ctx.set_ref(ref)
         ctx._ref_token = tok
+
+
+def invalidate_ref(ctx):
+    ctx._ref_token = None
 
 
 def ensure_q(ctx, Q, coeff_mode=0):
@@ -62,5 +78,7 @@ def ensure_q(ctx, Q, coeff_mode=0):
                          % (q.shape,))
     tok = (q.tobytes(), coeff_mode)
     if ctx._q_token != tok:
+        # Q and coeff_mode only: the motion-search parameters (window, stride,
+        # motion.SIMILARITY_THRESHOLD) keep whatever MotionProcessor pushed
         ctx.set_params(Q=q, coeff_mode=coeff_mode)
         ctx._q_token = tok

@@ -23,7 +23,7 @@ import numpy as np
 from DCTcompressor import DCTCompressor
 from frame import Frame, RowList
 from motion import MotionProcessor, _as_frame
-from _runtime import ensure_q, ensure_ref
+from _runtime import ensure_q, ensure_ref, invalidate_ref
 
 
 class Encoder:
@@ -39,6 +39,17 @@ class Encoder:
             block_size=block_size if dct_block_size is None else dct_block_size, device=device)
         self.with_DCT = with_DCT
         self.resident = (os.environ.get("VCS_RESIDENT") == "1") if resident is None else bool(resident)
+        # HBM budget of the planes kept behind Frame.r (49.8 MB per 1080p frame): past it the
+        # oldest frames' planes are spilled to host memory (VCS_RESIDENT_MAX_BYTES, default 64 GiB)
+        self.resident_max_bytes = int(os.environ.get("VCS_RESIDENT_MAX_BYTES", str(64 << 30)))
+        self._resident_bytes = 0
+        self._resident_fifo = []
+
+    def invalidate_ref(self):
+        """Call after editing an I frame IN PLACE when resident=True: the next P frame then
+        re-uploads its reference (the default mode hashes the whole I frame per P frame and
+        needs no such call)."""
+        invalidate_ref(self.MotionProcessor._ctx())
 
     def encode_frame(self, input_frame, frame_num):
         print("Encoding new frame of index", frame_num)
@@ -69,13 +80,22 @@ class Encoder:
         if self.with_DCT:
             dc._check(mp.shape[0], mp.shape[1])
         ctx = mp._ctx()
-        ensure_ref(ctx, _as_frame(ref, mp.shape, "ref_frame"))
+        # resident mode: the I frame is identified by (this encoder, its index) -- no per-frame
+        # hashing of 6-25 MB; default mode: full hash (the caller's array is aliased, encoder.py:42)
+        ensure_ref(ctx, _as_frame(ref, mp.shape, "ref_frame"),
+                   generation=(id(self), ref_idx) if self.resident else None)
         if self.with_DCT:
             ensure_q(ctx, dc.Q, dc.coeff_mode)
         keep = self.with_DCT and self.resident
         if keep:
             mv, planes, n_static = ctx.store_encode_p(cur)
             res = None
+            self._resident_fifo.append(planes)
+            self._resident_bytes += planes.nbytes
+            while self._resident_bytes > self.resident_max_bytes and len(self._resident_fifo) > 1:
+                old = self._resident_fifo.pop(0)
+                self._resident_bytes -= old.nbytes
+                old.spill()
         else:
             mv, planes, res, n_static = ctx.encode_p(cur, want_planes=bool(self.with_DCT),
                                                      want_res=not self.with_DCT)

@@ -546,6 +546,7 @@ int vcs_set_params(vcs_ctx *c, int win, int step, int64_t sim_thresh, const doub
                    int coeff_mode) {
     int rc = use(c);
     if (rc) return rc;
+    if (coeff_mode == VCS_KEEP) coeff_mode = c->coeff_mode;
     if (coeff_mode < VCS_COEFF_F64 || coeff_mode > VCS_COEFF_I16)
         return fail(c, VCS_E_ARG, "bad coeff_mode %d", coeff_mode);
     if (Q)
@@ -556,7 +557,7 @@ int vcs_set_params(vcs_ctx *c, int win, int step, int64_t sim_thresh, const doub
     int64_t saved_t = c->thresh64;
     if (win > 0) c->g.win = win;
     if (step > 0) c->g.step = step;
-    c->thresh64 = sim_thresh;
+    if (sim_thresh != VCS_KEEP_THRESH) c->thresh64 = sim_thresh;
     rc = refresh_me_geometry(c);
     if (rc) {
         c->g = saved;

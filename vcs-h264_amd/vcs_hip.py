@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VCS_HIP_LIB", os.path.join(_HERE, "lib", "libvcs_hip.so"))
 
 VCS_COEFF_F64, VCS_COEFF_F32, VCS_COEFF_I16 = 0, 1, 2
+KEEP_THRESH = -(1 << 63)  # VCS_KEEP_THRESH
 COEFF_DTYPES = {0: np.float64, 1: np.float32, 2: np.int16}
 T_ME, T_ENC_TAIL, T_DEC, T_AUX, T_COUNT = 0, 1, 2, 3, 4
 
@@ -165,11 +166,14 @@ class ResidentPlanes:
 
     def __init__(self, ctx, handle):
         self._ctx, self._h, self._host = ctx, handle, None
+        self._mode = ctx.coeff_mode
 
     def _planes(self):
         if self._host is None:
             c = self._ctx
-            out = np.zeros((3, c.H, c.W), c.coeff_dtype)
+            if self._h is None:
+                raise VcsError(-4, "resident planes were released before they were read")
+            out = np.zeros((3, c.H, c.W), COEFF_DTYPES[self._mode])
             c._ck(c._lib.vcs_store_planes(c._h, self._h, out.ctypes.data_as(_vp)))
             self._host = out
         return self._host
@@ -187,9 +191,24 @@ class ResidentPlanes:
     def resident(self):
         return self._h is not None and bool(self._ctx._h.value)
 
+    @property
+    def nbytes(self):
+        c = self._ctx
+        return 3 * c.H * c.W * np.dtype(COEFF_DTYPES[self._mode]).itemsize
+
+    def spill(self):
+        """Download the planes to host memory and free the HBM copy (the view keeps
+        working; the decoder then takes the host path)."""
+        if self._h is not None:
+            self._planes()
+            self.release()
+
     def release(self):
-        if self._h is not None and getattr(self._ctx, "_h", None) is not None and self._ctx._h.value:
-            self._ctx._lib.vcs_store_free(self._ctx._h, self._h)
+        if self._h is not None:
+            alive = getattr(self._ctx, "_h", None) is not None and self._ctx._h.value
+            # vcs_store_free accepts a NULL context: the HBM copy is freed even when the
+            # owning context was closed first
+            self._ctx._lib.vcs_store_free(self._ctx._h if alive else None, self._h)
         self._h = None
 
     def __del__(self):
@@ -244,8 +263,11 @@ class Context:
         return COEFF_DTYPES[self.coeff_mode]
 
     # -- parameters --------------------------------------------------------
-    def set_params(self, win=0, step=0, sim_thresh=2000, Q=None, coeff_mode=None):
+    def set_params(self, win=0, step=0, sim_thresh=None, Q=None, coeff_mode=None):
+        """Every argument left at its default keeps the context's current value
+        (sim_thresh=None -> VCS_KEEP_THRESH: pushing Q never resets the threshold)."""
         cm = self.coeff_mode if coeff_mode is None else int(coeff_mode)
+        sim_thresh = KEEP_THRESH if sim_thresh is None else int(sim_thresh)
         qp = None
         if Q is not None:
             Q = np.ascontiguousarray(np.asarray(Q, np.float64).reshape(3, 8, 8))
