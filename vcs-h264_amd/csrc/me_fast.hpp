@@ -95,8 +95,12 @@ __device__ __forceinline__ void me16_count13(const Me16Q &a, const Me16Q &c, uin
     for (int d = 0; d < 13; d++) t[d] &= 0x80808080u;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int d = 0; d < 13; d++)
-        asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[d & 3]) : "v"(t[d]));
+    for (int d = 0; d < 13; d++) {
+        // selects to v_bcnt_u32_b32 t, cnt; the empty asm pins the chain (as inline asm TEXT
+        // the instruction drew a 4-cycle s_nop from the hazard recogniser every fourth use)
+        cnt[d & 3] = (uint32_t)__builtin_popcount(t[d]) + cnt[d & 3];
+        asm volatile("" : "+v"(cnt[d & 3]));
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 // All 16 rows of two candidates per lane (p0: candidate `lane`, p1: candidate

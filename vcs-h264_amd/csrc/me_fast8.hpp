@@ -93,7 +93,10 @@ __device__ __forceinline__ uint32_t me8_count8(const uint4 &a0, const uint4 &a1,
     for (int d = 0; d < 8; d++) t[d] &= 0x80808080u;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int d = 0; d < 8; d++) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[d & 1]) : "v"(t[d]));
+    for (int d = 0; d < 8; d++) {
+        cnt[d & 1] = (uint32_t)__builtin_popcount(t[d]) + cnt[d & 1];  // v_bcnt_u32_b32 t, cnt
+        asm volatile("" : "+v"(cnt[d & 1]));
+    }
     __builtin_amdgcn_sched_barrier(0);
     return cnt[0] + cnt[1];
 }

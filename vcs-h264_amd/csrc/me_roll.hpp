@@ -62,17 +62,15 @@ __device__ __forceinline__ void me16r_offsets(const Geom &g, int lane, Me16rOffs
     }
 }
 
-// 16 rows of two candidates per lane out of the circular window.  base0/base1:
-// LDS byte offset of the candidate's first row; wrap0/wrap1: first row index
-// that lies past slot 63 (>= 16: never).  Otherwise as me16_rows.
-template <bool TWO, int ROWB>
+// 16 rows of one candidate per lane out of the circular window.  base0: LDS byte offset
+// of the candidate's first row; wrap0: first row index that lies past slot 63 (>= 16:
+// never).  Otherwise as me16_rows.
+template <int ROWB>
 __device__ __forceinline__ void me16r_rows(const uint8_t *s_win, const uint32_t *s_cur, int base0,
-                                           int wrap0, int base1, int wrap1, uint32_t (&acc0)[4],
-                                           uint32_t (&acc1)[4]) {
-    Me16Q c[2], a[2], b[2];
+                                           int wrap0, uint32_t (&acc0)[4]) {
+    Me16Q c[2], a[2];
     me16_ld(c[0], s_cur);
     me16_ld(a[0], s_win + base0);
-    if (TWO) me16_ld(b[0], s_win + base1);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const int cur = k & 1, nxt = cur ^ 1;
@@ -80,14 +78,9 @@ __device__ __forceinline__ void me16r_rows(const uint8_t *s_win, const uint32_t 
             me16_ld(c[nxt], s_cur + (k + 1) * kMe16CurPitch);
             const int o0 = base0 + (k + 1) * ROWB - ((k + 1) >= wrap0 ? 64 * ROWB : 0);
             me16_ld(a[nxt], s_win + o0);
-            if (TWO) {
-                const int o1 = base1 + (k + 1) * ROWB - ((k + 1) >= wrap1 ? 64 * ROWB : 0);
-                me16_ld(b[nxt], s_win + o1);
-            }
         }
         __builtin_amdgcn_sched_barrier(0);
         me16_count13(a[cur], c[cur], acc0);
-        if (TWO) me16_count13(b[cur], c[cur], acc1);
     }
 }
 
@@ -291,25 +284,20 @@ __global__ __launch_bounds__(64, 2) void k_me16r(
             const int ncand = nci * ncj;
             const int cand0 = lane, cand1 = lane + 64;
             const bool act0 = cand0 < ncand, act1 = cand1 < ncand;
-            int ci0 = 0, cj0 = 0, ci1 = 0, cj1 = 0;
+            int ci0 = 0, cj0 = 0;
             if (act0) { ci0 = cand0 / ncj; cj0 = cand0 - ci0 * ncj; }
-            if (act1) { ci1 = cand1 / ncj; cj1 = cand1 - ci1 * ncj; }
-            const int s0 = (B + STEP * ci0) & 63, s1 = (B + STEP * ci1) & 63;
-            const int base0 = s0 * ROWB + cj0 * 16, base1 = s1 * ROWB + cj1 * 16;
+            const int s0 = (B + STEP * ci0) & 63;
+            const int base0 = s0 * ROWB + cj0 * 16;
 
             uint32_t acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
-            if (ncand > 64) {
-                me16r_rows<false, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
+            me16r_rows<ROWB>(s_win, s_cur, base0, 64 - s0, acc0);
+            if (ncand > 64) {  // candidates 64..99: 2-row slabs
                 if (ncand == 100)
                     me16r_slabs<ROWB, 5>(s_win, s_cur, s_part, B, 36, ncj, lane);
                 else
                     me16r_slabs<ROWB, 0>(s_win, s_cur, s_part, B, ncand - 64, ncj, lane);
                 wave_lds_fence();
                 acc1[0] = s_part[min(lane, kMe16Pass2Max - 1)];
-            } else if (ncand > 64) {
-                me16r_rows<true, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
-            } else {
-                me16r_rows<false, ROWB>(s_win, s_cur, base0, 64 - s0, base1, 64 - s1, acc0, acc1);
             }
 
             const uint32_t n_lt0 = 768u + 64u - (acc0[0] + acc0[1] + acc0[2] + acc0[3]);

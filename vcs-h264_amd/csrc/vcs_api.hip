@@ -19,6 +19,7 @@
 #include "me_fast.hpp"
 #include "me_fast8.hpp"
 #include "me_roll.hpp"
+#include "me_group.hpp"
 #include "me_kernels.hpp"
 
 using namespace vcs;
@@ -227,8 +228,11 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     if (rc) return rc;
     if (roll) launch_me_roll_primer(c->stream, c->cus, ns, n);
     if (fast16) {
-        rc = roll ? launch_me_roll(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost,
-                                   ev.a, ev.b)
+        rc = roll ? (me16g_worthwhile(c->g, c->cus, n)
+                         ? launch_me_group(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv,
+                                           ns, cost, ev.a, ev.b)
+                         : launch_me_roll(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv,
+                                          ns, cost, ev.a, ev.b))
                   : launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost,
                                    ev.a, ev.b);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
