@@ -5,19 +5,33 @@ Workload (BASELINE.json metric: "macroblocks/sec (ME+DCT) at 1080p +-32px
 search"): a synthetic 1080p 30-frame GOP (1 I + 29 P frames, synth_gop), 16x16
 motion blocks -> +-32 px window on the reference's stride-5 grid, 8x8 DCT with
 the QF=50 tables, float64 coefficient planes.  One STEP = one pass of the hot
-path over the 29 P frames of the GOP: the motion-search kernel followed by the
+path over the 29 P frames of a GOP: the motion-search kernel followed by the
 fused MC + residual + colour + DCT + quantise kernel, with every input already
 resident in HBM and every output left in HBM.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling --
-one long GOP with 29*N P frames, rank r owns P frames [29r, 29r+29).  The only
-exchanges of the path are in the timed step: an RCCL broadcast of the I frame
-from rank 0 and an all-gather of the motion vectors; coefficient planes stay on
-the GPU that produced them.  PyTorch is used for that plumbing only.
+`value` is the COLD stream: the timed loop rotates through three resident copies
+of the GOP, so a step's 180 MB of input frames were last touched three steps ago
+and nothing of them is left in the 256 MB Infinity Cache -- what a stream of
+GOPs costs.  The same run also reports the loop over ONE resident GOP
+(`resident_one_gop`), which the cache flatters.
+
+N > 1: weak scaling -- one long GOP with 29*N P frames, GPU r owns P frames
+[29r, 29r+29).  The only exchanges of the path are inside the timed step: an RCCL
+broadcast of the I frame from GPU 0 and an all-gather of the motion vectors;
+coefficient planes stay on the GPU that produced them.  RCCL lives inside
+libvcs_hip.so (vcs_group_*); no PyTorch is imported.  Two launch forms:
+  python bench.py --gpus N                   one process, one context per GPU
+  python -m torch.distributed.run ... bench.py --gpus N
+                                             one process per GPU; the launcher only
+                                             hands out RANK / WORLD_SIZE / LOCAL_RANK
+`--strong` is BASELINE config 4: ONE 4K 30-frame GOP whose 29 P frames are split
+over the N GPUs (4 / 3 frames each at N = 8).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
+import io
 import json
 import os
 import sys
@@ -25,28 +39,23 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(REPO, "vcs-h264_amd")
-for p in (REPO, PKG):
+for p in (REPO, PKG, os.path.join(PKG, "InterframeCompression")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~5500 measured copy
+# issue cycles per wave-instruction on one SIMD, measured on this chip by tools/ub_valu.hip
+ISSUE_CYCLES = {"v_lerp_u8": 4, "v_and_b32": 2, "v_bcnt_u32_b32": 4, "other": 4}
 
 
-class _DevBytes:
-    """Zero-copy view of a libvcs_hip HBM buffer for torch (RCCL plumbing)."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1",
-                                         "data": (ptr, False), "version": 2}
-
-
-def cpu_baseline(H, W, bs, ref, frames, budget_s=12.0):
-    """The CPU oracle (our C restatement, `kind: port`) on the same workload, all
-    host cores via OpenMP, on a bounded sample of the GOP's P frames."""
-    from oracle import oracle
-    # the GPU box grants 16 host cores per GPU; never oversubscribe past the affinity mask
+def cpu_baseline(H, W, bs, ref, frames, budget_s=10.0):
+    """The CPU checker on the same workload (`kind: port`, our C restatement with OpenMP
+    on the box's host cores), on a bounded sample of the GOP's P frames; beside it the
+    structure-faithful NumPy loop (oracle/ref_loop.py, one thread), whose run time is tied
+    to the reference's own."""
+    from oracle import oracle, ref_loop
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     oracle.set_threads(cores)
     oracle.encode_p(frames[0][:64, :64].copy(), ref[:64, :64].copy(), bs)  # warm (build/load)
@@ -57,10 +66,102 @@ def cpu_baseline(H, W, bs, ref, frames, budget_s=12.0):
         done += 1
     dt = time.perf_counter() - t0
     N = (H // bs) * (W // bs)
-    return {"value": round(done * N / dt / 1e3, 3), "unit": "macroblocks/ms", "cores": cores,
-            "kind": "port",
-            "sample": "%d P-frame encodes cycling through the GOP (%dx%d, ME %dx%d + 8x8 DCT), "
-                      "oracle/vcs_oracle.c with OpenMP, %.1f s" % (done, W, H, bs, bs, dt)}
+    out = {"value": round(done * N / dt / 1e3, 3), "unit": "macroblocks/ms", "cores": cores,
+           "kind": "port",
+           "sample": "%d P-frame encodes cycling through the GOP (%dx%d, ME %dx%d + 8x8 DCT), "
+                     "oracle/vcs_oracle.c with OpenMP, %.1f s" % (done, W, H, bs, bs, dt)}
+    try:
+        mbs, t_me, t_dct = ref_loop.timed_sample(frames[0], ref, bs, oracle.make_q(50.0), budget_s=6.0)
+        out["reference_structured_loop"] = {
+            "value": round(mbs / (t_me + t_dct) / 1e3, 3), "me_only": round(mbs / t_me / 1e3, 3),
+            "unit": "macroblocks/ms", "cores": 1, "kind": "port",
+            "sample": "%d interior macroblocks of one P frame + their 8x8 tiles, per-block / per-tile "
+                      "NumPy loop with the reference's call structure (oracle/ref_loop.py); the "
+                      "unmodified reference ran the same search at 1.58 and this loop at 1.63 "
+                      "macroblocks/ms on one core of the build container (DESIGN.md 6)" % mbs}
+    except Exception as e:  # the headline never depends on it
+        out["reference_structured_loop"] = {"error": repr(e)}
+    return out
+
+
+def parity_columns(ctx, ref, frames, mv, slot0, bs):
+    """what was just timed, against the oracle, outside the timed region."""
+    from oracle import oracle
+    n = len(frames)
+    exact = sum(int(np.array_equal(mv[k], oracle.me(frames[k], ref, bs)[0])) for k in range(n))
+    k = n // 2
+    omv, oplanes, _ = oracle.encode_p(frames[k], ref, bs)
+    planes = ctx.gop_get_planes(slot0 + k)
+    dmax = float(np.max(np.abs(planes - oplanes)))
+    bits = bool(np.array_equal(planes.view(np.int64), oplanes.view(np.int64)))
+    dec = ctx.decode_p(mv[k], planes)
+    odec = oracle.decode_p(omv, oplanes, ref, bs)
+
+    def psnr(a, b):
+        mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+        return 99.0 if mse == 0 else 10.0 * np.log10(255.0 ** 2 / mse)
+    return {"mv_exact_fraction": exact / max(1, n), "frames_compared": n,
+            "planes_max_abs_diff": dmax, "planes_bit_identical": bits, "planes_frame": k,
+            "psnr_decoded_db": round(psnr(dec, frames[k]), 4),
+            "psnr_delta_db": round(psnr(dec, frames[k]) - psnr(odec, frames[k]), 6),
+            "decoded_pixels_identical": bool(np.array_equal(dec, odec)),
+            "oracle": "oracle/vcs_oracle.c (pinned to the reference's outputs, tests/golden)"}
+
+
+def host_path(H, W, bs, ref, frames, device, n_frames=48):
+    """SURVEY 8d "separately including H2D/D2H": the reference's own driving loop
+    (main.py:34-43: one Encoder.encode_frame per captured frame) through the drop-in
+    Encoder, frames produced into page-locked buffers, planes left in HBM."""
+    import encoder as E
+    import vcs_hip
+    from _runtime import release_contexts
+    ring = [vcs_hip.pinned_empty((H, W, 3)) for _ in range(6)]   # the frame feeder's buffers
+    pattern = ["I"] + ["P"] * 29
+    res = {}
+    for label, kw in (("pipelined", {}), ("synchronous", {"async_slots": 0})):
+        enc = E.Encoder(pattern=pattern, shape=[H, W], block_size=bs, with_DCT=True, dct_block_size=8,
+                        device=device, resident=True, **kw)
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink):   # encode_frame prints like the reference
+            ring[0][...] = ref
+            enc.encode_frame(ring[0], 0)
+            for k in range(1, 4):                # warm
+                ring[k % 5 + 1][...] = frames[k % len(frames)]
+                enc.encode_frame(ring[k % 5 + 1], k)
+            enc.flush()
+            t0 = time.perf_counter()
+            for k in range(4, 4 + n_frames):
+                if k % 30 == 0:                      # the next GOP's I frame
+                    enc.flush()
+                    enc.encode_frame(ring[0], k)
+                    continue
+                buf = ring[k % 5 + 1]
+                buf[...] = frames[k % len(frames)]   # the producer's write (e.g. a video decoder's)
+                enc.encode_frame(buf, k)
+            enc.flush()
+            dt = time.perf_counter() - t0
+        done = sum(1 for k in range(4, 4 + n_frames) if k % 30)
+        # the same loop without the encoder: what the producer's 6 MB write costs on its own
+        t1 = time.perf_counter()
+        for k in range(4, 4 + n_frames):
+            if k % 30:
+                ring[k % 5 + 1][...] = frames[k % len(frames)]
+        t_fill = time.perf_counter() - t1
+        N = (H // bs) * (W // bs)
+        res[label] = {"encode_frame_ms": round(dt / done * 1e3, 4),
+                      "producer_copy_ms": round(t_fill / done * 1e3, 4),
+                      "mb_per_ms": round(done * N / dt / 1e3, 1)}
+        last = enc.encoded_frames[-1]
+        res[label]["last_frame_blocks"] = len(last.mv)
+        del enc
+    release_contexts()
+    out = dict(res["pipelined"])
+    out["synchronous_encode_frame_ms"] = res["synchronous"]["encode_frame_ms"]
+    out["what"] = ("drop-in Encoder(resident=True).encode_frame per 1080p frame from page-locked "
+                   "buffers, H2D of the frame and D2H of its vectors included, planes stay in HBM; "
+                   "%d frames; the producer's own 6 MB write into the buffer is inside the loop "
+                   "(producer_copy_ms)" % n_frames)
+    return out
 
 
 def main():
@@ -68,214 +169,179 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--bs", type=int, default=16, help="motion block size (window = 2*bs)")
-    ap.add_argument("--frames", type=int, default=29, help="P frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=29, help="P frames per GPU per step (weak scaling)")
+    ap.add_argument("--strong", action="store_true",
+                    help="BASELINE config 4: ONE 3840x2160 30-frame GOP, its 29 P frames split over the GPUs")
+    ap.add_argument("--rotate-sets", type=int, default=3,
+                    help="resident copies of the GOP the timed loop rotates through (1 = re-encode one "
+                         "resident GOP, whose inputs then sit in the Infinity Cache)")
+    ap.add_argument("--group", action="store_true",
+                    help="take the multi-GPU code path (vcs_group_*, RCCL) even with one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (one-GOP loop, host path, parity, bandwidth)")
     ap.add_argument("--with-decode", action="store_true",
                     help="also time the decode kernel over the GOP (reported next to the line)")
     ap.add_argument("--same-ref", action="store_true",
-                    help="diagnostic: do not declare a new I frame per step (the per-reference sum "
-                         "table is then built once, outside the timed region)")
-    ap.add_argument("--slot-sets", type=int, default=1,
-                    help="diagnostic (single GPU): K resident copies of the GOP in K sets of slots, "
-                         "encoded in turn, so that consecutive steps neither read the same input "
-                         "frames nor write the same output planes (default 1: one resident GOP)")
-    ap.add_argument("--rotate-sets", type=int, default=3,
-                    help="single GPU: after the main measurement, repeat it rotating through this many "
-                         "resident copies of the GOP (inputs no longer in the 256 MB Infinity Cache "
-                         "from the previous step) and report it as `rotating_inputs`; 0 = skip")
-    ap.add_argument("--serial-comm", action="store_true",
-                    help="multi-GPU: broadcast -> kernels -> all-gather strictly in sequence "
-                         "instead of overlapping the collectives with the neighbouring GOPs' kernels")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="take the torch.distributed (RCCL) code path even with one rank")
+                    help="diagnostic: do not declare a new I frame per step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     args.steps = max(1, args.steps)
     args.warmup = max(0, args.warmup)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    if world > 1:
+        args.gpus = world                 # one process per GPU (launcher)
+    n_local = 1 if world > 1 else max(1, args.gpus)
+    n_gpus = world if world > 1 else n_local
+    use_group = args.group or n_gpus > 1
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a
-    # version banner when the process group comes up), so file descriptor 1 is pointed at
-    # stderr for the whole run and the line goes to a private copy of the original stdout.
+    # version banner), so file descriptor 1 is pointed at stderr for the whole run and the
+    # line goes to a private copy of the original stdout.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    dist = torch = None
-    use_dist = world > 1 or (args.force_dist and "RANK" in os.environ)
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import vcs_hip
     from synth import synth_gop
 
-    H, W, bs, n = args.height, args.width, args.bs, args.frames
-    ctx = vcs_hip.Context(H, W, bs, 8, device=local_rank)
+    H = args.height or (2160 if args.strong else 1080)
+    W = args.width or (3840 if args.strong else 1920)
+    bs = args.bs
+    sets = max(1, args.rotate_sets)
+    if world == 1 and vcs_hip.device_count() < n_local:
+        sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (n_local, vcs_hip.device_count()))
+    devices = [local_rank] if world > 1 else list(range(n_local))
+    ctxs = [vcs_hip.Context(H, W, bs, 8, device=d) for d in devices]
+    ctx = ctxs[0]
     N, F = ctx.N, ctx.F
-    # this rank's slice of the (long) GOP; synthetic, deterministic
-    ref, frames = synth_gop(H, W, n, seed=1234, first=1 + rank * n)
-    overlap = use_dist and not args.serial_comm
-    sets = max(1, args.slot_sets) if not use_dist else 1
-    rot = max(0, args.rotate_sets) if (not use_dist and sets == 1) else 0
-    ctx.gop_reserve(max(sets, rot) * n, with_decode=args.with_decode)
-    for k in range(max(sets, rot)):
-        ctx.gop_upload(k * n, frames)
-    set_state = {"k": 0}
-    if use_dist:
-        if rank == 0:
-            ctx.set_ref(ref)        # the I frame enters HBM on rank 0 only
-        ctx.ref_written()
-        ptr, nb = ctx.dev_ptr(1)
-        t_mv = torch.as_tensor(_DevBytes(ptr, nb), device="cuda")
-        ptr, nb = ctx.dev_ptr(0)
-        t_ref = torch.as_tensor(_DevBytes(ptr, nb), device="cuda")
-        if overlap:
-            # Collectives on their own stream, kernels on the context's stream, ordered by
-            # events only.  GOP k uses reference buffer k & 1: the I frame of GOP k+1 is
-            # broadcast into the other one while GOP k is being encoded (vcs_ref_swap then makes
-            # it current, no copy).  GOP k's motion vectors are copied aside behind its kernels
-            # (1 MB) and gathered from there while GOP k+1 is encoded into the same slots (writing
-            # the coefficient planes of alternate GOPs to alternate HBM regions costs the tail
-            # kernel 35 %, measured; so the slots stay put).
-            # Every rank enqueues the collectives in the same order:
-            # bcast(0), bcast(1), gather(0), bcast(2), gather(1), ...
-            try:   # plumbing that only exists in this mode; the same on every rank
-                ptr, nb = ctx.dev_ptr(3)
-                t_refs = [t_ref, torch.as_tensor(_DevBytes(ptr, nb), device="cuda")]
-                ctx.sync()
-                t_refs[1].copy_(t_refs[0])           # rank 0: both hold the decoder's output
-                xs = torch.cuda.ExternalStream(ctx.stream_handle(),
-                                               device=torch.device("cuda", local_rank))
-                cs = torch.cuda.Stream()
-            except Exception as e:                   # fall back to the sequential form
-                print("bench.py: overlapped collectives unavailable (%r), using --serial-comm" % (e,),
-                      file=sys.stderr)
-                overlap = False
-        if overlap:
-            mv_stage = [torch.empty_like(t_mv), torch.empty_like(t_mv)]
-            t_all = [torch.empty(world * t_mv.numel(), dtype=torch.uint8, device="cuda") for _ in range(2)]
-            ev_b = [torch.cuda.Event(), torch.cuda.Event()]   # broadcast into reference buffer i done (cs)
-            ev_c = [torch.cuda.Event(), torch.cuda.Event()]   # kernels of GOP k (k & 1 = i) + copy done (xs)
-            torch.cuda.synchronize()
-            state = {"k": 0}
-
-            def issue_bcast(k):
-                i = k & 1
-                with torch.cuda.stream(cs):
-                    cs.wait_event(ev_c[i])           # GOP k-2 no longer reads this reference buffer
-                    dist.broadcast(t_refs[i], src=0)
-                    ev_b[i].record(cs)
-
-            issue_bcast(0)
+    n_total = 29 if args.strong else args.frames * n_gpus   # P frames of the (long) GOP
+    group = None
+    if use_group:
+        if world > 1:
+            uid = vcs_hip.rendezvous_unique_id(rank, world)
+            group = vcs_hip.Group.from_rank(ctx, uid, world, rank)
+            group.barrier()
+            vcs_hip.rendezvous_cleanup(rank, world)
         else:
-            ctx.sync()
-            t_all = torch.empty(world * t_mv.numel(), dtype=torch.uint8, device="cuda")
+            group = vcs_hip.Group(ctxs)
+        group.layout(n_total, with_decode=args.with_decode, sets=sets)
+        shards = [group.shard(i) for i in range(group.n_local)]
+    else:
+        shards = [(0, n_total)]
+        ctx.gop_reserve(sets * n_total, with_decode=args.with_decode)
+    # synthetic, deterministic; each process builds only the slices its GPUs own
+    ref = None
+    local_frames = []
+    for first, count in shards:
+        r, fr = synth_gop(H, W, count, seed=1234, first=1 + first)
+        ref = r
+        local_frames.append(fr)
+    for k in range(sets):
+        if group is not None:
+            group.use_set(k)
+            for (first, count), fr in zip(shards, local_frames):
+                if count:
+                    group.upload(first, fr)
+        else:
+            ctx.gop_upload(k * n_total, local_frames[0])
+    if group is not None:
+        group.use_set(0)
+        group.set_ref(ref)               # the I frame enters HBM on GPU 0 only (no-op elsewhere)
     else:
         ctx.set_ref(ref)
+    state = {"k": 0}
 
-    def step():
-        if overlap:
-            k = state["k"]
-            i = k & 1
-            state["k"] = k + 1
-            issue_bcast(k + 1)                       # next GOP's I frame, beside this GOP's kernels
-            # One wait per GOP, on an event that was signalled long ago (during the previous GOP's
-            # kernels): this GOP's I frame has arrived -- and, since the collectives run in order
-            # on their stream and gather(k-2) was enqueued before bcast(k), GOP k-2's vectors
-            # have left mv_stage[i].  (A wait on something that has only just finished costs the
-            # kernels' stream ~20 us of queue latency: tried with the vector copy on the other
-            # stream.)
-            xs.wait_event(ev_b[i])
-            if k:
-                ctx.ref_swap()                       # buffer i becomes the reference (new sum table)
-            else:
-                ctx.ref_written()
-            ctx.gop_encode(0, n)                     # ME kernel + fused tail kernel
-            with torch.cuda.stream(xs):
-                mv_stage[i].copy_(t_mv, non_blocking=True)   # 1 MB aside: GOP k+1 reuses the slots
-                ev_c[i].record(xs)
-            with torch.cuda.stream(cs):
-                cs.wait_event(ev_c[i])
-                dist.all_gather_into_tensor(t_all[i], mv_stage[i])   # motion-vector collection
+    def step(rot=sets):
+        k = state["k"] % rot
+        state["k"] += 1
+        if group is not None:
+            group.use_set(k)
+            group.encode()                # I-frame broadcast (prefetched) + ME + tail + MV all-gather
+            group.prefetch_ref()          # the next GOP's I frame, beside this GOP's kernels
             return
-        if use_dist:
-            ts = torch.cuda.current_stream().cuda_stream
-            dist.broadcast(t_ref, src=0)             # I frame over xGMI (after the previous
-            ctx.stream_wait(ts)                      # step's all-gather; our stream waits for it)
-        # every step is a new GOP: the per-reference work (k_me16's sum table) is
-        # redone inside the timed region, once per GOP as in a real encode
+        # every step is a new GOP: the per-reference work (the sum table) is redone inside
+        # the timed region, once per GOP as in a real encode
         if not args.same_ref:
             ctx.ref_written()
-        if sets > 1:
-            set_state["k"] = (set_state["k"] + 1) % sets
-        ctx.gop_encode(set_state["k"] * n, n)        # ME kernel + fused tail kernel
-        if use_dist:
-            ctx.stream_signal(ts)                    # collectives wait for the kernels, GPU-side
-            dist.all_gather_into_tensor(t_all, t_mv)  # motion-vector collection
+        ctx.gop_encode(k * n_total, n_total)   # ME kernel + fused tail kernel
 
     def fence():
-        ctx.sync()
-        if use_dist:
-            torch.cuda.synchronize()                 # all torch streams, the collectives' included
-            dist.barrier()
-            torch.cuda.synchronize()
+        for c in ctxs:
+            c.sync()
+        if group is not None:
+            group.sync()
+            group.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ctx.timing_enable(not os.environ.get("VCS_BENCH_NO_EVENTS"))   # diagnostic: cost of the event brackets
-    ctx.timing_reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    t_enq = time.perf_counter() - t0                 # host time to enqueue the K steps
-    fence()
-    dt = time.perf_counter() - t0
-    ms, launches = ctx.timing()
-    ctx.timing_enable(False)
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(rot, steps, warm):
+        state["k"] = 0
+        for _ in range(warm):
+            step(rot)
+        fence()
+        for c in ctxs:
+            c.timing_enable(not os.environ.get("VCS_BENCH_NO_EVENTS"))
+            c.timing_reset()
+            c.me_cycles(reset=True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(rot)
+        t_enq = time.perf_counter() - t0
+        fence()
+        dt = time.perf_counter() - t0
+        per = [c.timing() for c in ctxs]
+        cyc = [c.me_cycles(reset=True) for c in ctxs]
+        for c in ctxs:
+            c.timing_enable(False)
+        if group is not None:
+            dt = group.max_over_ranks(dt)
+        return dt, t_enq, per, cyc
 
-    # parity guard on what was just timed: searched fraction + MV checksum
-    mv, ns = ctx.gop_get_mv(0, n)
-    searched = 1.0 - float(ns.sum()) / max(1, n * N)
+    dt, t_enq, per, cyc = timed(sets, args.steps, max(args.warmup, sets if sets > 1 else 0))
+    ms, launches = per[0]
+
+    # what was just timed: vectors of the last GOP (all shards'), static counts
+    if group is not None:
+        mv_all, ns_all = group.get_mv()
+        first0, count0 = shards[0]
+        mv0, ns0 = mv_all[first0:first0 + count0], ns_all[first0:first0 + count0]
+        last_set = (state["k"] - 1) % sets
+        slot0 = last_set * count0
+    else:
+        last_set = (state["k"] - 1) % sets
+        slot0 = last_set * n_total
+        mv0, ns0 = ctx.gop_get_mv(slot0, n_total)
+        mv_all, ns_all, count0 = mv0, ns0, n_total
+    searched = 1.0 - float(ns_all.sum()) / max(1, len(ns_all) * N)
 
     if rank == 0:
-        units = world * n * N * args.steps              # macroblocks, whole job
+        units = n_total * N * args.steps                # macroblocks, whole job
         value = units / dt / 1e3                        # macroblocks per millisecond
-        # algorithmic HBM bytes per macroblock: ME reads cur + ref and
-        # writes the vectors; the tail reads cur + ref + vectors, writes 3 f64 planes
+        n0 = count0                                     # frames per launch on GPU 0
+        ms_step = dt / args.steps * 1e3
+        # algorithmic HBM bytes per macroblock: ME reads cur + ref and writes the
+        # vectors; the tail reads cur + ref + vectors, writes 3 f64 planes
         per_mb = {vcs_hip.T_ME: (2 * F + 4 * N) / N, vcs_hip.T_ENC_TAIL: (10 * F + 4 * N) / N}
-        names = {vcs_hip.T_ME: "k_me16r" if bs == 16 else "k_me8" if bs == 8 else "k_me_generic",
-                 vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
-        # PMC-measured HBM bytes per launch of the same workload (profiles/hbm_traffic.json,
-        # produced by profiles/collect.sh; FETCH_SIZE doubled per the gfx950 correction)
+        me_name = ("k_me16g" if bs == 16 and n0 >= 4 else "k_me16r/k_me16" if bs == 16
+                   else "k_me8" if bs == 8 else "k_me_generic")
+        names = {vcs_hip.T_ME: me_name, vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
+        tj = {}
         traffic = {}
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "hbm_traffic.json")))
             wl = tj["workload"]
-            if (wl["H"], wl["W"], wl["frames_per_launch"], wl["me_bs"]) == (H, W, n, bs):
+            if (wl["H"], wl["W"], wl["frames_per_launch"], wl["me_bs"]) == (H, W, n0, bs):
                 traffic = {k: v["hbm_bytes_corrected"] for k, v in tj["kernels"].items()}
         except (OSError, KeyError, ValueError):
             pass
 
         def roof(slot):
             avg_ms = ms[slot] / max(1, int(launches[slot]))
-            alg = per_mb[slot] * n * N
+            alg = per_mb[slot] * n0 * N
             ach = alg / (avg_ms * 1e-3) / 1e9
             return {"bound": "hbm", "kernel": names[slot], "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -284,104 +350,125 @@ def main():
 
         dom = max(per_mb, key=lambda k: ms[k])
         other = vcs_hip.T_ENC_TAIL if dom == vcs_hip.T_ME else vcs_hip.T_ME
+        transport = vcs_hip.TRANSPORTS.get(group.transport, "?") if group is not None else None
+        if args.strong:
+            wl = ("configs[3]: ONE synthetic %dx%d 30-frame GOP, its 29 P frames split over %d GPU(s) "
+                  "(%s frames each)" % (W, H, n_gpus, "/".join(str(c) for c in sorted(
+                      {vcs_hip.shard_frames(29, n_gpus, r)[1] for r in range(n_gpus)}, reverse=True))))
+        else:
+            wl = ("configs[2]-shaped: synthetic %dx%d 30-frame GOP (1 I + %d P per GPU)" % (W, H, args.frames))
+        wl += (", %dx%d motion blocks, +-%d px stride-%d grid search, 8x8 DCT QF=50, float64 planes; "
+               "the timed loop rotates through %d resident copies of the GOP (cold inputs)"
+               % (bs, bs, 2 * bs, round(bs / 3), sets))
         out = {
-            "metric": "macroblocks/ms (16x16, ME+DCT encode) at 1080p +-32px search",
+            "metric": "macroblocks/ms (16x16, ME+DCT encode) at %s +-32px search" % ("4K" if H >= 2160 else "1080p"),
             "value": round(value, 2), "unit": "macroblocks/ms",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "u8 (motion search) + f64 (DCT)", "data": "synthetic",
-            "config": {"workload": "configs[2]-shaped: synthetic %dx%d 30-frame GOP (1 I + %d P per "
-                                   "GPU), %dx%d motion blocks, +-%d px stride-%d grid search, 8x8 "
-                                   "DCT QF=50, float64 planes" % (W, H, n, bs, bs, 2 * bs,
-                                                                  round(bs / 3)),
-                       "frames_per_step_per_gpu": n, "macroblocks_per_frame": N,
+            "config": {"workload": wl,
+                       "frames_per_step_gpu0": n0, "frames_per_step_total": n_total,
+                       "macroblocks_per_frame": N,
                        "searched_block_fraction": round(searched, 4),
                        "resident_gop_sets_encoded_in_turn": sets,
-                       "parallelism": "P frames sharded over %d GPU(s)" % world,
-                       "collectives": ("none" if not use_dist else
-                                       "RCCL broadcast (I frame) + all-gather (vectors) per GOP, " +
-                                       ("overlapped with the neighbouring GOPs' kernels" if overlap
-                                        else "in sequence with the kernels"))},
+                       "parallelism": ("P frames sharded over %d GPU(s), %s"
+                                       % (n_gpus, "one process per GPU" if world > 1 else
+                                          "one process, one context per GPU" if n_gpus > 1 else "single context")),
+                       "collectives": ("none" if group is None else
+                                       "in-library RCCL broadcast (I frame) + all-gather (vectors) per GOP: " + transport)},
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "kernel_ms_per_step": {"me": round(ms[vcs_hip.T_ME] / args.steps, 4),
                                    "enc_tail": round(ms[vcs_hip.T_ENC_TAIL] / args.steps, 4)},
             "roofline": roof(dom),
             "roofline_second_kernel": roof(other),
+            # the whole step against HBM: 10F + 4N algorithmic bytes per P frame on GPU 0
+            "pipeline_hbm": {"bytes_per_step": int((10 * F + 4 * N) * n0),
+                             "gbs": round((10 * F + 4 * N) * n0 / (ms_step * 1e-3) / 1e9, 1),
+                             "frac": round((10 * F + 4 * N) * n0 / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "north_star asks for >= 0.40; the search is vector-issue bound (below)"},
         }
-        if names[vcs_hip.T_ME] == "k_me16r":
-            # the motion search is bound by vector-ALU issue, not by HBM: say how close it
-            # is to THAT roof (wave-instructions per launch from profiles/r01 PMC, 16-lane
-            # SIMDs issue one wave64 instruction per 4 cycles)
-            valu_per_mb = 1216.0
-            try:  # the committed PMC count for this workload, if present
-                kj = tj["kernels"]["k_me16r"]
-                valu_per_mb = round(kj["valu_wave_insts_per_dispatch"] /
-                                    (tj["workload"]["frames_per_launch"] * N), 1)
+        if me_name == "k_me16g":
+            # The motion search is bound by vector-ALU issue, not by HBM: how close it is to THAT
+            # roof, priced with the clock the chip held in this run (longest workgroup lifetime in
+            # shader cycles / launch duration) and per-opcode issue cycles (tools/ub_valu.hip).
+            me_ms = ms[vcs_hip.T_ME] / max(1, int(launches[vcs_hip.T_ME]))
+            core = 26 * 13                       # row steps x dwords per macroblock: lerp, and, bcnt each
+            valu_per_mb = 1142.0
+            try:
+                kj = tj["kernels"]["k_me16g"]
+                valu_per_mb = round(kj["valu_wave_insts_per_dispatch"] / (tj["workload"]["frames_per_launch"] * N), 1)
             except Exception:
                 pass
-            peak = 256 * 4 * 2.4e9 / 4
-            me_ms = ms[vcs_hip.T_ME] / max(1, int(launches[vcs_hip.T_ME]))
-            ach = valu_per_mb * n * N / (me_ms * 1e-3)
-            out["k_me16r_valu_issue"] = {"achieved_ginst_s": round(ach / 1e9, 1),
-                                        "peak_ginst_s": round(peak / 1e9, 1),
-                                        "frac": round(ach / peak, 3),
-                                        "valu_wave_insts_per_macroblock": valu_per_mb}
-        try:
-            out["hbm_measured_gbs"] = {"copy_read_plus_write": round(ctx.measure_copy_bw(1 << 28, 5), 0),
-                                       "fill_write_only": round(ctx.measure_fill_bw(1 << 28, 5), 0)}
-        except vcs_hip.VcsError:
-            pass
-        if rot > 1:
-            # The main loop re-encodes ONE resident GOP: its 29 input frames (180 MB) are read
-            # again every step and stay in the 256 MB Infinity Cache (the planes are written
-            # with non-temporal stores and do not evict them).  Same measurement, rotating
-            # through `rot` resident copies so that a step's inputs were last touched rot
-            # steps ago: what a stream of GOPs costs when nothing comes from that cache.
-            def rstep(k):
-                ctx.ref_written()
-                ctx.gop_encode((k % rot) * n, n)
-            for k in range(rot):
-                rstep(k)
-            ctx.sync()
-            ctx.timing_enable(True)
-            ctx.timing_reset()
-            t1 = time.perf_counter()
-            for k in range(args.steps):
-                rstep(k)
-            ctx.sync()
-            dtr = time.perf_counter() - t1
-            msr, lr = ctx.timing()
-            ctx.timing_enable(False)
-            out["rotating_inputs"] = {
-                "resident_gop_sets": rot, "value": round(n * N * args.steps / dtr / 1e3, 2),
-                "unit": "macroblocks/ms", "ms_per_step": round(dtr / args.steps * 1e3, 4),
-                "kernel_ms_per_step": {"me": round(msr[vcs_hip.T_ME] / args.steps, 4),
-                                       "enc_tail": round(msr[vcs_hip.T_ENC_TAIL] / args.steps, 4)}}
+            other_insts = max(0.0, valu_per_mb - 3 * core)
+            cyc_per_mb = core * (ISSUE_CYCLES["v_lerp_u8"] + ISSUE_CYCLES["v_and_b32"] +
+                                 ISSUE_CYCLES["v_bcnt_u32_b32"]) + other_insts * ISSUE_CYCLES["other"]
+            clock_ghz = cyc[0] / (me_ms * 1e-3) / 1e9 if cyc[0] else None
+            simds = 256 * 4
+            out["k_me16g_valu_issue"] = {
+                "clock_ghz_measured": round(clock_ghz, 3) if clock_ghz else None,
+                "valu_wave_insts_per_macroblock": valu_per_mb,
+                "issue_cycles_per_macroblock": round(cyc_per_mb, 1),
+                "frac": (round(cyc_per_mb * n0 * N / (simds * clock_ghz * 1e9 * me_ms * 1e-3), 3)
+                         if clock_ghz else None),
+                "how": "issue cycles of the kernel's vector instructions (PMC count in profiles/, "
+                       "v_lerp_u8 4 / v_and 2 / v_bcnt 4 / other 4 cycles) over 1,024 SIMDs x measured "
+                       "clock x launch time"}
+        if not args.no_extras:
+            try:
+                out["hbm_measured_gbs"] = {"copy_read_plus_write": round(ctx.measure_copy_bw(1 << 28, 5), 0),
+                                           "fill_write_only": round(ctx.measure_fill_bw(1 << 28, 5), 0)}
+            except vcs_hip.VcsError:
+                pass
+    if not args.no_extras and sets > 1:
+        # the loop over ONE resident GOP: its 29 input frames (180 MB) are read again every
+        # step and stay in the 256 MB Infinity Cache -- every rank takes part (collectives)
+        dt1, _, per1, _ = timed(1, args.steps, 2)
+        if rank == 0:
+            m1, l1 = per1[0]
+            out["resident_one_gop"] = {
+                "value": round(n_total * N * args.steps / dt1 / 1e3, 2), "unit": "macroblocks/ms",
+                "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                "kernel_ms_per_step": {"me": round(m1[vcs_hip.T_ME] / args.steps, 4),
+                                       "enc_tail": round(m1[vcs_hip.T_ENC_TAIL] / args.steps, 4)},
+                "note": "inputs re-read from the Infinity Cache every step; not the headline"}
+    if rank == 0:
         if args.with_decode:
             # second line of SURVEY 8d: dequantise + IDCT + colour + MC-add over the same GOP
             ctx.timing_enable(True)
             ctx.timing_reset()
             for _ in range(5):
-                ctx.gop_decode(0, n)
+                ctx.gop_decode(slot0, n0)
             ms2, l2 = ctx.timing()
             ctx.timing_enable(False)
             dec_ms = ms2[vcs_hip.T_DEC] / max(1, int(l2[vcs_hip.T_DEC]))
-            alg = (9 * F + 4 * N + F) * n  # planes + ref + vectors in, frame out
+            alg = (9 * F + 4 * N + F) * n0  # planes + ref + vectors in, frame out
             out["decode"] = {"kernel": "k_idct<residual>", "avg_launch_ms": round(dec_ms, 4),
                              "achieved_gbs": round(alg / (dec_ms * 1e-3) / 1e9, 1),
                              "encode_plus_decode_macroblocks_per_ms":
-                                 round(n * N / (dt / args.steps * 1e3 + dec_ms), 1)}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(H, W, bs, ref, frames)
+                                 round(n0 * N / (dt / args.steps * 1e3 + dec_ms), 1)}
+        if not args.no_extras:
+            try:
+                out["parity"] = parity_columns(ctx, ref, local_frames[0], mv0, slot0, bs)
+            except Exception as e:
+                out["parity"] = {"error": repr(e)}
+        if not args.no_cpu_baseline and n_gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(H, W, bs, ref, local_frames[0])
         else:
             out["cpu_baseline"] = None
+    if group is not None:
+        group.barrier()
+        group.close()
+    for c in ctxs:
+        c.close()
+    if rank == 0:
+        if not args.no_extras and n_gpus == 1 and not args.strong and bs == 16:
+            try:
+                out["host_path"] = host_path(H, W, bs, ref, local_frames[0], devices[0])
+            except Exception as e:
+                out["host_path"] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    ctx.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

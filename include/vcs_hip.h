@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VCS_ABI_VERSION 1
+#define VCS_ABI_VERSION 2
 
 enum {
     VCS_OK = 0,
@@ -41,7 +41,8 @@ enum {
     VCS_E_HIP = -2,     /* a HIP runtime call failed                        */
     VCS_E_NOMEM = -3,   /* allocation failed                                */
     VCS_E_STATE = -4,   /* call sequence error (e.g. no reference set)      */
-    VCS_E_RANGE = -5    /* a motion vector / block would read out of frame  */
+    VCS_E_RANGE = -5,   /* a motion vector / block would read out of frame  */
+    VCS_E_COMM = -6     /* an RCCL call failed (multi-GPU group)             */
 };
 
 enum {                  /* coefficient plane element type                   */
@@ -152,6 +153,101 @@ int vcs_store_decode_p(vcs_ctx *ctx, const int16_t *mv, const vcs_planes *h,
                        uint8_t *bgr_out);
 int vcs_store_free(vcs_ctx *ctx, vcs_planes *h);
 
+/* ---- pipelined single-frame feeder (next row N3) -------------------------- */
+/* main.py:34-43 calls Encoder.encode_frame once per captured frame.  These entry
+ * points do what vcs_store_encode_p does without a host synchronisation per
+ * frame: K staging slots, the upload of frame k on a copy stream beside the
+ * kernels of frame k-1 and the vector download of frame k-2.
+ *   vcs_async_reserve   K slots (>= 2 to overlap anything).
+ *   vcs_encode_p_async  enqueue one P frame in a free slot; the planes handle is
+ *                       valid at once (its contents when the slot completes).
+ *                       `cur_bgr` is read until the upload has run: page-locked
+ *                       buffers (vcs_host_alloc) must stay untouched until
+ *                       vcs_wait(slot); pageable ones are staged by the runtime
+ *                       before the call returns.
+ *   vcs_wait            block until the slot's frame is done; its motion vectors
+ *                       and static count.  The slot is free again afterwards.
+ * vcs_set_ref between frames is allowed (it waits for the frames in flight).   */
+int vcs_async_reserve(vcs_ctx *ctx, int n_slots);
+int vcs_encode_p_async(vcs_ctx *ctx, int slot, const uint8_t *cur_bgr, vcs_planes **handle_out);
+int vcs_wait(vcs_ctx *ctx, int slot, int16_t *mv_out, uint32_t *n_static);
+
+/* ---- multi-GPU GOP encode, RCCL inside the library ------- */
+/* Every P frame depends only on the raw I frame of its GOP (encoder.py:51-52):
+ * the P frames are dealt to the shards (one context per GPU) in contiguous
+ * chunks, chunk sizes differ by at most one, earlier shards take the larger
+ * ones (vcs_shard_frames).  Exchanges: ncclBroadcast of the I frame from shard
+ * 0 into every context's resident reference buffer, ncclAllGather of motion
+ * vectors and static counts.  Coefficient planes stay on their GPU.
+ *
+ * vcs_encode_gop: the whole GOP in one call, single process, one context per
+ * device.  frames: n_frames x F, frame 0 = the I frame, frames 1.. = its P
+ * frames in order (encoder.py:25).  mv_out: (n_frames-1) x N x [dx,dy] int16.
+ * planes_out (nullable): (n_frames-1) x 3 x H x W coefficients (downloaded from
+ * the GPU that holds them).  The group behind it (communicators, streams) is
+ * created on the first call and lives until one of the contexts is destroyed.
+ * Contexts on pairwise distinct devices use RCCL; contexts that all share ONE
+ * device (RCCL refuses duplicate devices) run the same schedule with
+ * device-to-device copies -- the sharding / gather logic on a one-GPU box.    */
+int vcs_shard_frames(int n_frames, int world, int rank, int *first, int *count);
+int vcs_encode_gop(vcs_ctx *const *ctxs, int n_ctx, const uint8_t *frames, int n_frames,
+                   int16_t *mv_out, void *planes_out);
+
+/* The pieces of vcs_encode_gop, for callers that keep GOPs resident, pipeline
+ * them (bench.py) or run one process per GPU.
+ *   vcs_group_create       single process: context i is shard i of n_ctx.
+ *   vcs_comm_unique_id + vcs_group_create_rank
+ *                          one process per GPU (ncclCommInitRank): rank 0 makes
+ *                          the 128-byte id, every rank passes the same bytes.
+ *   vcs_group_layout       shard table for a GOP of n_p_frames P frames; reserves
+ *                          the contexts' GOP slots (vcs_gop_reserve).
+ *   vcs_group_upload       P frames [first_p, first_p+n) of the GOP from host
+ *                          memory; each local shard takes its part of the range.
+ *   vcs_group_set_ref      stages the next GOP's I frame on shard 0's GPU (no-op in
+ *                          processes that do not hold shard 0).
+ *   vcs_group_prefetch_ref enqueues the broadcast of the staged I frame into the
+ *                          contexts' ALTERNATE reference buffers, on the
+ *                          collectives' stream -- beside the kernels of the GOP
+ *                          being encoded.  Optional: vcs_group_encode does it
+ *                          itself when nothing was prefetched.
+ *   vcs_group_encode       asynchronous: makes the prefetched buffer current,
+ *                          motion search + encoder tail over the shard's frames,
+ *                          copies the vectors aside and all-gathers them on the
+ *                          collectives' stream.
+ *   vcs_group_get_mv       waits, then all P frames' vectors / static counts in
+ *                          GOP order (from the gathered copy on local shard 0).
+ *   vcs_group_max_f64      max over all processes of *v (and a barrier).
+ * Planes / decoded frames of local shard i: vcs_gop_get_planes(ctx_i, slot) with
+ * slot = P-frame index - first (vcs_group_shard).
+ * VCS_GROUP_SERIAL=1: collectives on the kernels' stream, strictly in sequence. */
+typedef struct vcs_group vcs_group;
+#define VCS_UNIQUE_ID_BYTES 128
+int vcs_comm_unique_id(void *id, size_t bytes);
+int vcs_group_create(vcs_ctx *const *ctxs, int n_ctx, vcs_group **out);
+int vcs_group_create_rank(vcs_ctx *ctx, const void *unique_id, int world, int rank,
+                          vcs_group **out);
+int vcs_group_destroy(vcs_group *g);
+const char *vcs_group_last_error(const vcs_group *g);
+/* transport: 1 = RCCL overlapped, 2 = RCCL serial, 3 = same-device copies overlapped, 4 = serial */
+int vcs_group_info(vcs_group *g, int *world, int *rank0, int *n_local, int *transport);
+int vcs_group_layout(vcs_group *g, int n_p_frames, int with_decode);
+/* n_sets resident copies of the GOP's slots per shard (set k of a shard with `count`
+ * frames = context slots [k*count, (k+1)*count)); vcs_group_use_set picks the one that
+ * upload / encode / decode work on (bench.py rotates through them so that consecutive
+ * steps find nothing of their input in the Infinity Cache).                        */
+int vcs_group_layout_sets(vcs_group *g, int n_p_frames, int with_decode, int n_sets);
+int vcs_group_use_set(vcs_group *g, int set);
+int vcs_group_shard(vcs_group *g, int local_idx, int *first, int *count);
+int vcs_group_upload(vcs_group *g, int first_p, int n, const uint8_t *frames);
+int vcs_group_set_ref(vcs_group *g, const uint8_t *ref_bgr);
+int vcs_group_prefetch_ref(vcs_group *g);
+int vcs_group_encode(vcs_group *g);
+int vcs_group_decode(vcs_group *g);
+int vcs_group_sync(vcs_group *g);
+int vcs_group_get_mv(vcs_group *g, int16_t *mv_out, uint32_t *n_static_out);
+int vcs_group_max_f64(vcs_group *g, double *v);
+int vcs_group_barrier(vcs_group *g);
+
 /* ---- batched, HBM-resident GOP path ------------------------------------ */
 /* All P frames of a GOP depend only on the raw I frame (encoder.py:51-52), so
  * a whole GOP is one launch chain.  Slots 0..n-1 hold P frames; outputs stay
@@ -225,6 +321,11 @@ int vcs_stream_handle(vcs_ctx *ctx, void **stream);
 int vcs_timing_enable(vcs_ctx *ctx, int on);
 int vcs_timing_reset(vcs_ctx *ctx);
 int vcs_timing(vcs_ctx *ctx, double *ms_out, uint64_t *launches_out, int n);
+/* With timing on, the shared-window search kernel (k_me16g) records the longest lifetime of
+ * any of its workgroups in shader-clock cycles (s_memtime), maximum over the launches since
+ * the last reset: divided by that launch's duration it is the clock the chip held under
+ * this load (bench.py prices the kernel's vector-issue utilisation with it).            */
+int vcs_me_cycles(vcs_ctx *ctx, uint64_t *cycles, int reset);
 /* Bytes/s of a device-to-device copy of `bytes` (the practical HBM roof).   */
 int vcs_measure_copy_bw(vcs_ctx *ctx, size_t bytes, int iters, double *gbps_out);
 /* Bytes/s of a device memset of `bytes` (the practical HBM write-only roof).  */

@@ -11,7 +11,7 @@ sys.path[:0] = [REPO, os.path.join(REPO, "vcs-h264_amd")]
 
 
 class OracleBackend:
-    """Same four methods as gop.HipGopBackend, computed by the CPU oracle."""
+    """set_ref / encode / planes, computed by the CPU oracle (stands in for a GPU context)."""
 
     def __init__(self, H, W, me_bs):
         from oracle import oracle

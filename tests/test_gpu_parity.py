@@ -481,8 +481,8 @@ def test_gop_encoder_single_rank(vh, oracle):
     for k in range(n):
         omv, oplanes, ons = oracle.encode_p(frames[k], ref, 16)
         assert np.array_equal(mv[k], omv) and ns[k] == ons
-        assert np.array_equal(enc.backend.planes(k), oplanes)
-    enc.backend.close()
+        assert np.array_equal(enc.planes(k), oplanes)
+    enc.close()
 
 
 @pytest.mark.parametrize("sfx", ["", "2"])

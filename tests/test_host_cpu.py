@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(vh):
         assert hasattr(lib, s), "libvcs_hip.so does not export %s" % s
         assert s in vh.SIGNATURES, "vcs_hip.py has no prototype for %s" % s
     assert sorted(vh.SIGNATURES) == syms
-    assert vh.load().vcs_abi_version() == 1
+    assert vh.load().vcs_abi_version() == 2
 
 
 def test_host_only_entry_points_match_golden(vh):
@@ -144,3 +144,66 @@ def test_rowlist_reads_like_a_list_of_pairs():
         v[4]
     with pytest.raises(ValueError):
         RowList(np.zeros((3, 3)))
+
+
+def test_shard_table_of_the_library_matches_the_contract(vh):
+    """vcs_shard_frames (the library's own dealing of P frames to GPUs): contiguous,
+    sizes differ by at most one, earlier shards take the larger chunks."""
+    for n in (0, 1, 5, 29, 30, 64, 232):
+        for world in (1, 2, 3, 4, 8):
+            pos = 0
+            counts = []
+            for r in range(world):
+                first, count = vh.shard_frames(n, world, r)
+                assert first == pos
+                pos += count
+                counts.append(count)
+            assert pos == n and max(counts) - min(counts) <= 1
+            assert counts == sorted(counts, reverse=True)
+    assert [vh.shard_frames(29, 8, r)[1] for r in range(8)] == [4, 4, 4, 4, 4, 3, 3, 3]   # config 4
+    with pytest.raises(ValueError):
+        vh.shard_frames(5, 2, 2)
+
+
+def test_rendezvous_hands_rank0s_id_to_every_rank(vh, tmp_path):
+    """The file rendezvous bench.py uses under torch.distributed.run (no PyTorch in the
+    ranks): three processes, rank 0's 128 bytes reach the others; a stale file of another
+    launch (different tag) is not picked up."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import vcs_hip\n"
+            "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+            "u = vcs_hip.rendezvous_unique_id(r, w, timeout_s=60, make_id=lambda: bytes([7 + r]) * 128)\n"
+            "open(os.path.join(%r, 'id%%d' %% r), 'wb').write(u)\n" % (os.path.join(REPO, "vcs-h264_amd"), str(tmp_path)))
+    tag = "test_%d" % os.getpid()
+    procs = []
+    for r in (2, 1, 0):   # rank 0 last: the others must wait for it
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="3", VCS_RENDEZVOUS_TAG=tag)
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env))
+    assert all(p.wait(timeout=120) == 0 for p in procs)
+    ids = [open(tmp_path / ("id%d" % r), "rb").read() for r in range(3)]
+    assert ids[0] == bytes([7]) * 128 and ids[1] == ids[0] and ids[2] == ids[0]
+    os.environ["VCS_RENDEZVOUS_TAG"] = tag
+    try:
+        vh.rendezvous_cleanup(0, 3)
+        with pytest.raises(TimeoutError):
+            vh.rendezvous_unique_id(1, 3, timeout_s=0.3)
+    finally:
+        del os.environ["VCS_RENDEZVOUS_TAG"]
+
+
+def test_reference_structured_loop_equals_the_oracle():
+    """oracle/ref_loop.py (the slow, structure-faithful CPU baseline) computes what the C
+    oracle computes."""
+    from oracle import oracle, ref_loop
+    from synth import synth_static
+    ref, cur = synth_static(64, 96, seed=9, bs=16, frac=0.4)
+    for bs in (8, 16):
+        mv, ns = ref_loop.me(cur, ref, bs)
+        omv, ons = oracle.me(cur, ref, bs)
+        assert np.array_equal(mv, omv) and ns == ons
+    Q = oracle.make_q(50.0)
+    planes, ycc = oracle.compress(cur, Q, want_ycc=True)
+    for ch in range(3):
+        got = ref_loop.compress_plane(ycc[..., ch].astype(np.int16) - 128, Q[ch])
+        assert np.max(np.abs(got - planes[ch])) < 1e-9   # NumPy's matmul order, not the oracle's fma chain

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools_gpu_ab.sh "ENV=VAL ..." ...   -> one bench line summary per env set
 for cfg in "$@"; do
-  out=$(env $cfg timeout -k 10 120 python bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_EXTRA 2>&1 | tail -1)
+  out=$(env $cfg timeout -k 10 120 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras $BENCH_EXTRA 2>&1 | tail -1)
   python - "$cfg" "$out" <<'PY'
 import sys, json
 cfg, out = sys.argv[1], sys.argv[2]

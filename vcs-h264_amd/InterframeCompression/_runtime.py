@@ -21,6 +21,7 @@ def get_context(H, W, me_bs, device=0):
         ctx = vcs_hip.Context(H, W, me_bs, 8, device)
         ctx._ref_token = None
         ctx._q_token = None
+        ctx._pending = None
         _CONTEXTS[key] = ctx
     return ctx
 
@@ -82,3 +83,50 @@ def ensure_q(ctx, Q, coeff_mode=0):
         # motion.SIMILARITY_THRESHOLD) keep whatever MotionProcessor pushed
         ctx.set_params(Q=q, coeff_mode=coeff_mode)
         ctx._q_token = tok
+
+
+# ---- pipelined frame feeder (vcs_encode_p_async / vcs_wait) -------------
+class Pending:
+    """One P frame in flight through the context's staging slots.  complete() blocks until
+    its motion vectors are back (idempotent); the input array is kept alive until then."""
+
+    __slots__ = ("ctx", "slot", "cur", "mv", "n_static", "on_done")
+
+    def __init__(self, ctx, slot, cur, on_done=None):
+        self.ctx, self.slot, self.cur, self.on_done = ctx, slot, cur, on_done
+        self.mv = self.n_static = None
+
+    def complete(self):
+        if self.mv is None:
+            mv, ns = self.ctx.wait(self.slot)
+            self.mv, self.n_static = mv.astype(np.int64), ns
+            if self.ctx._pending[self.slot] is self:
+                self.ctx._pending[self.slot] = None
+            self.cur = None
+            if self.on_done is not None:
+                self.on_done(self)
+        return self.mv
+
+
+def submit_async(ctx, cur, slots, on_done=None):
+    """Enqueue `cur` in the next staging slot of `ctx` (completing whatever still occupies
+    it).  Returns (ResidentPlanes, Pending)."""
+    if getattr(ctx, "_pending", None) is None or len(ctx._pending) != slots:
+        flush_async(ctx)
+        ctx.async_reserve(slots)
+        ctx._pending = [None] * slots
+        ctx._next_slot = 0
+    s = ctx._next_slot
+    ctx._next_slot = (s + 1) % slots
+    if ctx._pending[s] is not None:
+        ctx._pending[s].complete()
+    planes = ctx.encode_p_async(s, cur)
+    p = Pending(ctx, s, cur, on_done)
+    ctx._pending[s] = p
+    return planes, p
+
+
+def flush_async(ctx):
+    for p in list(getattr(ctx, "_pending", None) or []):
+        if p is not None:
+            p.complete()

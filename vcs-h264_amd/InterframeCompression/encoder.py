@@ -21,15 +21,15 @@ import math
 import numpy as np
 
 from DCTcompressor import DCTCompressor
-from frame import Frame, RowList
+from frame import Frame, LazyRowList, RowList
 from motion import MotionProcessor, _as_frame
-from _runtime import ensure_q, ensure_ref, invalidate_ref
+from _runtime import ensure_q, ensure_ref, flush_async, invalidate_ref, submit_async
 
 
 class Encoder:
 
     def __init__(self, pattern, shape, block_size, with_DCT, *, dct_block_size=None, device=0,
-                 resident=None):
+                 resident=None, async_slots=None):
         self.ref_frames = []
         self.encoded_frames = []
         self.pattern = pattern
@@ -44,6 +44,16 @@ class Encoder:
         self.resident_max_bytes = int(os.environ.get("VCS_RESIDENT_MAX_BYTES", str(64 << 30)))
         self._resident_bytes = 0
         self._resident_fifo = []
+        # resident mode is pipelined: encode_frame returns once the frame is ENQUEUED (its
+        # upload overlaps the previous frame's kernels); Frame.mv waits on first access.
+        # async_slots=0 keeps one host synchronisation per frame (VCS_ASYNC_SLOTS overrides).
+        if async_slots is None:
+            async_slots = int(os.environ.get("VCS_ASYNC_SLOTS", "3"))
+        self.async_slots = int(async_slots) if self.resident else 0
+
+    def flush(self):
+        """Wait for every frame still in flight (pipelined resident mode)."""
+        flush_async(self.MotionProcessor._ctx())
 
     def invalidate_ref(self):
         """Call after editing an I frame IN PLACE when resident=True: the next P frame then
@@ -87,15 +97,12 @@ class Encoder:
         if self.with_DCT:
             ensure_q(ctx, dc.Q, dc.coeff_mode)
         keep = self.with_DCT and self.resident
+        if keep and self.async_slots >= 1:
+            return self._submit_P_frame(ctx, mp, cur, frame_num, ref_idx)
         if keep:
             mv, planes, n_static = ctx.store_encode_p(cur)
             res = None
-            self._resident_fifo.append(planes)
-            self._resident_bytes += planes.nbytes
-            while self._resident_bytes > self.resident_max_bytes and len(self._resident_fifo) > 1:
-                old = self._resident_fifo.pop(0)
-                self._resident_bytes -= old.nbytes
-                old.spill()
+            self._track_resident(planes)
         else:
             mv, planes, res, n_static = ctx.encode_p(cur, want_planes=bool(self.with_DCT),
                                                      want_res=not self.with_DCT)
@@ -113,6 +120,30 @@ class Encoder:
                          block_coords=RowList(self._coords(mp)), index=frame_num, ref_idx=ref_idx)
         return Frame("P", motion_vectors=mv.astype(np.int64).tolist(), residuals=r,
                      block_coords=mp._block_coords().tolist(), index=frame_num, ref_idx=ref_idx)
+
+    def _track_resident(self, planes):
+        self._resident_fifo.append(planes)
+        self._resident_bytes += planes.nbytes
+        while self._resident_bytes > self.resident_max_bytes and len(self._resident_fifo) > 1:
+            old = self._resident_fifo.pop(0)
+            self._resident_bytes -= old.nbytes
+            old.spill()
+
+    def _submit_P_frame(self, ctx, mp, cur, frame_num, ref_idx):
+        """Pipelined form of the P-frame path: upload + kernels + vector download are only
+        ENQUEUED here (vcs_encode_p_async); the progress lines that need the result are
+        printed when it arrives.  `cur` must not be rewritten in place before then when it
+        lives in page-locked memory (vcs_hip.pinned_empty): call flush() first."""
+        def done(p):
+            mp.last_static_blocks = p.n_static
+            num_static = int(np.count_nonzero((p.mv == 0).all(axis=1)))
+            print("There are", num_static, "static blocks out of", len(p.mv), "blocks")
+        planes, pending = submit_async(ctx, cur, self.async_slots, done)
+        self._track_resident(planes)
+        print("Finished processing motion. Got motion vectors.")
+        print("begin compression")
+        return Frame("P", motion_vectors=LazyRowList(pending), residuals=planes,
+                     block_coords=RowList(self._coords(mp)), index=frame_num, ref_idx=ref_idx)
 
     def _coords(self, mp):
         c = getattr(self, "_coords_cache", None)

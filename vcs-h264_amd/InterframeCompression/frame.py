@@ -70,3 +70,20 @@ class RowList:
 
     def __repr__(self):
         return "RowList(%d x 2)" % len(self)
+
+
+class LazyRowList(RowList):
+    """A RowList whose array is still on its way back from the GPU (the pipelined frame
+    feeder, Encoder(resident=True)): the first access of any kind waits for it."""
+
+    __slots__ = ("_pending",)
+
+    def __init__(self, pending):
+        self._pending = pending
+
+    @property
+    def _a(self):
+        return self._pending.complete()
+
+    def __repr__(self):
+        return "LazyRowList(%s)" % ("pending" if self._pending.mv is None else "%d x 2" % len(self))

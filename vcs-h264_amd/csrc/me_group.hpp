@@ -157,8 +157,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WPS, WPS
 void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
              Geom g, int n_frames, int seg_len, const uint32_t *__restrict__ sums,
              int16_t *__restrict__ mv, uint32_t *__restrict__ n_static,
-             unsigned long long *__restrict__ cost_out) {
+             unsigned long long *__restrict__ cost_out, unsigned long long *__restrict__ clk_out) {
     using Cfg = Me16gCfg<W>;
+    // shader-clock cycles this workgroup lives (s_memtime): the longest-lived workgroup's
+    // count over the launch's duration is the clock the chip held under this load
+    const unsigned long long clk0 = clk_out ? __builtin_amdgcn_s_memtime() : 0ull;
     constexpr int ROWB = kMe16gRowB, RING = kMe16gRing;
     constexpr int BS = 16, WIN = 32, STEP = 5, NG = kMe16Groups;
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe16gWinBytes + W * kMe16gWaveBytes];
@@ -378,6 +381,7 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
         A = Bq;
       }
     }
+    if (clk_out && tid == 0) atomicMax(clk_out, __builtin_amdgcn_s_memtime() - clk0);
 }
 
 // VCS_ME16_GROUP: frames per workgroup of the shared-window kernel (1, 2, 4, 8; default 4);
@@ -427,8 +431,8 @@ inline bool me16g_worthwhile(const Geom &g, int cus, int n) {
 template <int W, int WPS>
 inline int launch_me_group_t(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                              const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
-                             uint32_t *ns, unsigned long long *cost, hipEvent_t ev_start,
-                             hipEvent_t ev_stop) {
+                             uint32_t *ns, unsigned long long *cost, unsigned long long *clk,
+                             hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int seg = me16g_seg_len(g.nby);
     const long long units = (long long)((n + W - 1) / W) * ((g.nby + seg - 1) / seg) * g.nbx;
     // resident workgroups: WPS waves per SIMD = 4 * WPS waves per CU = 4 * WPS / W workgroups
@@ -442,18 +446,18 @@ inline int launch_me_group_t(const Geom &g, hipStream_t stream, int cus, const u
     const long long cap = (units + 7) / 8 * 8;
     dim3 gd((unsigned)(grid > cap ? cap : grid)), block(64 * W);
     hipExtLaunchKernelGGL((k_me16g<W, WPS>), gd, block, 0, stream, ev_start, ev_stop, 0, ref, curs,
-                          stride, g, n, seg, (const uint32_t *)sums, mv, ns, cost);
+                          stride, g, n, seg, (const uint32_t *)sums, mv, ns, cost, clk);
     return 0;
 }
 
 inline int launch_me_group(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                            const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
-                           uint32_t *ns, unsigned long long *cost, hipEvent_t ev_start = nullptr,
-                           hipEvent_t ev_stop = nullptr) {
+                           uint32_t *ns, unsigned long long *cost, unsigned long long *clk = nullptr,
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     if ((long long)g.N * n > 0x7FFFFFFF) return -1;
 #define VCS_ME16G(Wv, Pv)                                                                         \
     return launch_me_group_t<Wv, Pv>(g, stream, cus, ref, curs, stride, n, sums, mv, ns, cost,    \
-                                     ev_start, ev_stop)
+                                     clk, ev_start, ev_stop)
     const int w = me16g_group(), p = me16g_wps();
     if (w == 1) { if (p == 2) VCS_ME16G(1, 2); if (p == 4) VCS_ME16G(1, 4); VCS_ME16G(1, 3); }
     if (w == 2) { if (p == 2) VCS_ME16G(2, 2); if (p == 4) VCS_ME16G(2, 4); VCS_ME16G(2, 3); }

@@ -36,6 +36,16 @@ struct EvPair {
 
 }  // namespace
 
+struct vcs_group;
+struct PlaneSlab;
+
+struct AsyncSlot {  // one frame in flight through vcs_encode_p_async
+    uint8_t *d_cur = nullptr;
+    int16_t *d_mv = nullptr, *h_mv = nullptr;  // N x 2 vectors + the static count behind them
+    hipEvent_t ev_in = nullptr, ev_kern = nullptr, ev_out = nullptr;
+    bool busy = false;
+};
+
 struct vcs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -48,6 +58,7 @@ struct vcs_ctx {
     bool me_fast_ok = false;
     bool me_fast8_ok = false;
     uint32_t *d_sums = nullptr;  // k_me16: per-reference sum(r) table
+    unsigned long long *d_clk = nullptr;  // k_me16g: longest workgroup lifetime in shader cycles (timing on)
     bool sums_valid = false;
     int cus = 256;         // compute units of the device
     // single-frame buffers
@@ -70,6 +81,19 @@ struct vcs_ctx {
     uint32_t *g_ns = nullptr;
     void *g_planes = nullptr;
     hipEvent_t xev = nullptr;  // cross-stream ordering with a foreign (torch / RCCL) stream
+    vcs_group *group = nullptr;  // multi-GPU group this context is a shard of (vcs_multi.hpp)
+    // pipelined single-frame feeder (vcs_async_reserve)
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<AsyncSlot> aslots;
+    PlaneSlab *slab = nullptr;   // where the next resident planes handle is carved from
+    // CU-split pipelining of the GOP path (VCS_SPLIT_CUS = c > 0): the HBM-bound encoder tail
+    // of GOP k runs on c CUs (c / 8 per XCD) beside the vector-issue-bound search of GOP k+1
+    // on the other 256 - c; two CU-masked streams, ordered by events
+    int split_cus = 0;
+    hipStream_t s_me = nullptr, s_tail = nullptr;
+    hipEvent_t ev_main = nullptr, ev_me = nullptr, ev_tail = nullptr;
+    bool split_pending = false;  // work on s_me / s_tail that c->stream has not been joined with
+    int tail_first = 0, tail_n = 0;  // slots the last tail launch reads and writes
     // timing
     bool timing = false;
     std::vector<EvPair> pending;
@@ -230,7 +254,7 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     if (fast16) {
         rc = roll ? (me16g_worthwhile(c->g, c->cus, n)
                          ? launch_me_group(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv,
-                                           ns, cost, ev.a, ev.b)
+                                           ns, cost, c->timing ? c->d_clk : nullptr, ev.a, ev.b)
                          : launch_me_roll(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv,
                                           ns, cost, ev.a, ev.b))
                   : launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost,
@@ -377,9 +401,33 @@ int check_mv(vcs_ctx *c, const int16_t *mv, const int32_t *coords, int n) {
     return VCS_OK;
 }
 
-int use(vcs_ctx *c) {
+int use(vcs_ctx *c, bool join = true) {
     if (!c) return fail(nullptr, VCS_E_ARG, "null context");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (join && c->split_pending) {  // everything else is ordered behind the split streams' work
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_me, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_tail, 0));
+        c->split_pending = false;
+    }
+    return VCS_OK;
+}
+
+// Two CU-masked streams: bit i of the mask is CU i / 8 of XCD i % 8 (tools/cu_mask_probe.hip),
+// so the first c bits are c / 8 CUs on every XCD.
+int ensure_split(vcs_ctx *c) {
+    if (c->s_me) return VCS_OK;
+    const int words = (c->cus + 31) / 32;
+    std::vector<uint32_t> m_tail(words, 0u), m_me(words, 0u);
+    const char *sh = getenv("VCS_SPLIT_SHARED");  // diagnostic: both streams on every CU
+    for (int i = 0; i < c->cus; i++) {
+        if (sh && sh[0] == '1') { m_tail[i / 32] |= 1u << (i % 32); m_me[i / 32] |= 1u << (i % 32); }
+        else (i < c->split_cus ? m_tail : m_me)[i / 32] |= 1u << (i % 32);
+    }
+    HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->s_me, (uint32_t)words, m_me.data()));
+    HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->s_tail, (uint32_t)words, m_tail.data()));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_me, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
     return VCS_OK;
 }
 
@@ -389,10 +437,96 @@ void free_gop(vcs_ctx *c) {
     c->slots = 0;
 }
 
+void free_async(vcs_ctx *c) {
+    for (auto &s : c->aslots) {
+        hipFree(s.d_cur); hipFree(s.d_mv);
+        if (s.h_mv) hipHostFree(s.h_mv);
+        if (s.ev_in) hipEventDestroy(s.ev_in);
+        if (s.ev_kern) hipEventDestroy(s.ev_kern);
+        if (s.ev_out) hipEventDestroy(s.ev_out);
+    }
+    c->aslots.clear();
+    if (c->s_in) hipStreamDestroy(c->s_in);
+    if (c->s_out) hipStreamDestroy(c->s_out);
+    c->s_in = c->s_out = nullptr;
+}
+
+}  // namespace
+
+// ---- HBM-resident coefficient planes: handles carved out of slabs -----------------
+// One hipMalloc per frame (49.8 MB at 1080p) costs more than the frame's kernels and
+// synchronises the device; handles are therefore carved out of slabs of up to 16 frames.
+// A slab is freed when its last handle is (handles may outlive their context).
+struct PlaneSlab {
+    void *base = nullptr;
+    size_t each = 0;
+    int cap = 0, used = 0, live = 0;
+    bool current = false;  // some context still carves from it
+};
+struct vcs_planes {
+    void *d = nullptr;
+    size_t bytes = 0;
+    int coeff_mode = 0;
+    int H = 0, W = 0;
+    PlaneSlab *slab = nullptr;
+};
+
+namespace {
+
+void slab_release(PlaneSlab *sl) {
+    if (!sl || sl->live > 0) return;
+    if (sl->current) { sl->used = 0; return; }  // empty and still current: start over
+    hipFree(sl->base);
+    delete sl;
+}
+
+int planes_alloc(vcs_ctx *c, vcs_planes **out) {
+    const size_t bytes = planes_bytes(c), each = round_up(bytes + 64, 256);
+    PlaneSlab *sl = c->slab;
+    if (sl && (sl->each != each || sl->used == sl->cap)) {
+        sl->current = false;
+        slab_release(sl);
+        sl = c->slab = nullptr;
+    }
+    if (!sl) {
+        sl = new (std::nothrow) PlaneSlab();
+        if (!sl) return fail(c, VCS_E_NOMEM, "out of host memory");
+        const size_t want = ((size_t)1 << 30) / each;
+        sl->cap = (int)(want < 1 ? 1 : want > 16 ? 16 : want);
+        sl->each = each;
+        hipError_t e = hipMalloc(&sl->base, each * sl->cap);
+        if (e != hipSuccess && sl->cap > 1) {  // memory is tight: one frame at a time
+            sl->cap = 1;
+            e = hipMalloc(&sl->base, each);
+        }
+        if (e != hipSuccess) {
+            delete sl;
+            return fail(c, VCS_E_NOMEM, "hipMalloc(planes): %s", hipGetErrorString(e));
+        }
+        sl->current = true;
+        c->slab = sl;
+    }
+    vcs_planes *h = new (std::nothrow) vcs_planes();
+    if (!h) return fail(c, VCS_E_NOMEM, "out of host memory");
+    h->d = (char *)sl->base + (size_t)sl->used * each;
+    h->bytes = bytes;
+    h->coeff_mode = c->coeff_mode;
+    h->H = c->g.H;
+    h->W = c->g.W;
+    h->slab = sl;
+    sl->used++;
+    sl->live++;
+    *out = h;
+    return VCS_OK;
+}
+
 }  // namespace
 
 // ==========================================================================
 extern "C" {
+
+int vcs_group_destroy(vcs_group *g);
+int vcs_store_free(vcs_ctx *c, vcs_planes *h);
 
 int vcs_abi_version(void) { return VCS_ABI_VERSION; }
 
@@ -496,6 +630,11 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     CREATE_TRY(hipSetDevice(device));
     CREATE_TRY(hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device));
     if (c->cus < 1) c->cus = 1;
+    {
+        const char *e = getenv("VCS_SPLIT_CUS");
+        const int v = e ? atoi(e) : 0;
+        c->split_cus = (v >= 8 && v <= c->cus - 8) ? v / 8 * 8 : 0;
+    }
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&c->xev, hipEventDisableTiming));
     // the reference carries slack rows: k_me16 fetches its window 64 rows deep
@@ -503,6 +642,8 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     CREATE_TRY(hipMalloc(&c->d_ref, c->Fs + me_fast_ref_slack(g)));
     CREATE_TRY(hipMemset(c->d_ref, 0, c->Fs + me_fast_ref_slack(g)));
     CREATE_TRY(hipMalloc(&c->d_sums, me_fast_sums_bytes(g)));
+    CREATE_TRY(hipMalloc(&c->d_clk, 16));
+    CREATE_TRY(hipMemset(c->d_clk, 0, 16));
     CREATE_TRY(hipMalloc(&c->d_cur, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_a, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_b, c->Fs));
@@ -530,8 +671,21 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
 
 int vcs_ctx_destroy(vcs_ctx *c) {
     if (!c) return VCS_OK;
+    if (c->group) vcs_group_destroy(c->group);  // detaches every member context
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->s_out) hipStreamSynchronize(c->s_out);
+    free_async(c);
+    if (c->s_me) { hipStreamSynchronize(c->s_me); hipStreamDestroy(c->s_me); }
+    if (c->s_tail) { hipStreamSynchronize(c->s_tail); hipStreamDestroy(c->s_tail); }
+    if (c->ev_main) hipEventDestroy(c->ev_main);
+    if (c->ev_me) hipEventDestroy(c->ev_me);
+    if (c->ev_tail) hipEventDestroy(c->ev_tail);
+    if (c->slab) {
+        c->slab->current = false;
+        slab_release(c->slab);
+        c->slab = nullptr;
+    }
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto &p : c->pool) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     free_gop(c);
@@ -539,6 +693,7 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     hipFree(c->d_coords); hipFree(c->d_cost); hipFree(c->d_ns); hipFree(c->d_planes);
     hipFree(c->d_DQ);
     hipFree(c->d_sums);
+    hipFree(c->d_clk);
     hipFree(c->d_intra);
     if (c->xev) hipEventDestroy(c->xev);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -734,13 +889,6 @@ int vcs_decode_p(vcs_ctx *c, const int16_t *mv, const void *planes, uint8_t *bgr
 // in HBM behind an opaque handle: the encoder returns only the motion vectors,
 // the decoder consumes the handle directly, and the planes are downloaded only
 // if somebody actually looks at them.
-struct vcs_planes {
-    void *d = nullptr;
-    size_t bytes = 0;
-    int coeff_mode = 0;
-    int H = 0, W = 0;
-};
-
 int vcs_store_encode_p(vcs_ctx *c, const uint8_t *cur, int16_t *mv_out, uint32_t *n_static,
                        vcs_planes **handle_out) {
     int rc = use(c);
@@ -749,17 +897,8 @@ int vcs_store_encode_p(vcs_ctx *c, const uint8_t *cur, int16_t *mv_out, uint32_t
     *handle_out = nullptr;
     if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
     if ((rc = need_dct_geometry(c))) return rc;
-    vcs_planes *h = new (std::nothrow) vcs_planes();
-    if (!h) return fail(c, VCS_E_NOMEM, "out of host memory");
-    h->bytes = planes_bytes(c);
-    h->coeff_mode = c->coeff_mode;
-    h->H = c->g.H;
-    h->W = c->g.W;
-    hipError_t e = hipMalloc(&h->d, h->bytes + 64);
-    if (e != hipSuccess) {
-        delete h;
-        return fail(c, VCS_E_NOMEM, "hipMalloc(planes): %s", hipGetErrorString(e));
-    }
+    vcs_planes *h = nullptr;
+    if ((rc = planes_alloc(c, &h))) return rc;
     const size_t N = c->g.N;
     rc = VCS_OK;
     hipError_t e2 = hipMemcpyAsync(c->d_cur, cur, c->F, hipMemcpyHostToDevice, c->stream);
@@ -777,8 +916,7 @@ int vcs_store_encode_p(vcs_ctx *c, const uint8_t *cur, int16_t *mv_out, uint32_t
     e2 = hipStreamSynchronize(c->stream);
     if (!rc && e2 != hipSuccess) rc = fail(c, VCS_E_HIP, "sync: %s", hipGetErrorString(e2));
     if (rc) {
-        hipFree(h->d);
-        delete h;
+        vcs_store_free(c, h);
         return rc;
     }
     if (n_static) *n_static = ns;
@@ -824,8 +962,12 @@ int vcs_store_free(vcs_ctx *c, vcs_planes *h) {
         hipSetDevice(c->device);
         if (c->stream) hipStreamSynchronize(c->stream);
     }
-    hipFree(h->d);
+    PlaneSlab *sl = h->slab;
     delete h;
+    if (sl) {
+        sl->live--;
+        slab_release(sl);
+    }
     return VCS_OK;
 }
 
@@ -874,16 +1016,44 @@ int vcs_gop_upload(vcs_ctx *c, int first, int n, const uint8_t *frames) {
 }
 
 int vcs_gop_encode(vcs_ctx *c, int first, int n) {
-    int rc = use(c);
+    const bool split = c && c->split_cus > 0 && c->g.N > 0 && n > 0;
+    int rc = use(c, /*join=*/!split);
     if (rc || (rc = slot_range(c, first, n))) return rc;
     if (!c->ref_valid) return fail(c, VCS_E_STATE, "no reference frame set (vcs_set_ref)");
     size_t N = c->g.N;
     const uint8_t *curs = c->g_cur + (size_t)first * c->Fs;
     int16_t *mv = c->g_mv + (size_t)first * N * 2;
-    rc = launch_me(c, c->d_ref, curs, c->Fs, n, mv, c->g_ns + first, nullptr);
-    if (rc) return rc;
     size_t pe = (size_t)3 * c->g.H * c->g.W;
     void *planes = (char *)c->g_planes + (size_t)first * planes_bytes(c);
+    if (split) {
+        // search on the big CU partition, tail on the small one; the NEXT call's search may
+        // start while this call's tail is still running (different slots) -- see vcs_ctx
+        if ((rc = ensure_split(c))) return rc;
+        hipStream_t main = c->stream;
+        const int cus = c->cus;
+        HIP_TRY(c, hipEventRecord(c->ev_main, main));          // uploads, set_ref, ... so far
+        HIP_TRY(c, hipStreamWaitEvent(c->s_me, c->ev_main, 0));
+        const bool overlap = c->split_pending && first < c->tail_first + c->tail_n && c->tail_first < first + n;
+        if (overlap) HIP_TRY(c, hipStreamWaitEvent(c->s_me, c->ev_tail, 0));  // same slots: in sequence
+        c->stream = c->s_me;
+        { const char *sh = getenv("VCS_SPLIT_SHARED"); c->cus = (sh && sh[0] == '1') ? cus : cus - c->split_cus; }
+        rc = launch_me(c, c->d_ref, curs, c->Fs, n, mv, c->g_ns + first, nullptr);
+        c->cus = cus;
+        if (!rc) {
+            hipEventRecord(c->ev_me, c->s_me);
+            hipStreamWaitEvent(c->s_tail, c->ev_me, 0);
+            c->stream = c->s_tail;
+            rc = launch_fdct<1>(c, VCS_T_ENC_TAIL, curs, c->Fs, c->d_ref, mv, n, planes, pe);
+            hipEventRecord(c->ev_tail, c->s_tail);
+        }
+        c->stream = main;
+        c->split_pending = true;
+        c->tail_first = first;
+        c->tail_n = n;
+        return rc;
+    }
+    rc = launch_me(c, c->d_ref, curs, c->Fs, n, mv, c->g_ns + first, nullptr);
+    if (rc) return rc;
     if (N == 0)  // no full motion block: the prediction is all zero (motion.py:45-46)
         return launch_fdct<0>(c, VCS_T_ENC_TAIL, curs, c->Fs, nullptr, nullptr, n, planes, pe);
     return launch_fdct<1>(c, VCS_T_ENC_TAIL, curs, c->Fs, c->d_ref, mv, n, planes, pe);
@@ -1144,6 +1314,18 @@ int vcs_timing(vcs_ctx *c, double *ms_out, uint64_t *launches_out, int n) {
     return VCS_OK;
 }
 
+int vcs_me_cycles(vcs_ctx *c, uint64_t *cycles, int reset) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!cycles) return fail(c, VCS_E_ARG, "null pointer");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long v = 0;
+    HIP_TRY(c, hipMemcpy(&v, c->d_clk, 8, hipMemcpyDeviceToHost));
+    *cycles = v;
+    if (reset) HIP_TRY(c, hipMemset(c->d_clk, 0, 8));
+    return VCS_OK;
+}
+
 int vcs_measure_copy_bw(vcs_ctx *c, size_t bytes, int iters, double *gbps_out) {
     int rc = use(c);
     if (rc) return rc;
@@ -1194,3 +1376,5 @@ int vcs_measure_fill_bw(vcs_ctx *c, size_t bytes, int iters, double *gbps_out) {
 }
 
 }  // extern "C"
+
+#include "vcs_multi.hpp"

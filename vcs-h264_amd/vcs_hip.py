@@ -52,6 +52,32 @@ SIGNATURES = {
     "vcs_store_planes": (ctypes.c_int, [_c_ctx, _vp, _vp]),
     "vcs_store_decode_p": (ctypes.c_int, [_c_ctx, _i16p, _vp, _u8p]),
     "vcs_store_free": (ctypes.c_int, [_c_ctx, _vp]),
+    "vcs_async_reserve": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
+    "vcs_encode_p_async": (ctypes.c_int, [_c_ctx, ctypes.c_int, _u8p, ctypes.POINTER(_vp)]),
+    "vcs_wait": (ctypes.c_int, [_c_ctx, ctypes.c_int, _i16p, _u32p]),
+    "vcs_shard_frames": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int)] * 2),
+    "vcs_encode_gop": (ctypes.c_int, [ctypes.POINTER(_c_ctx), ctypes.c_int, _u8p, ctypes.c_int, _i16p,
+                                      _vp]),
+    "vcs_comm_unique_id": (ctypes.c_int, [_vp, ctypes.c_size_t]),
+    "vcs_group_create": (ctypes.c_int, [ctypes.POINTER(_c_ctx), ctypes.c_int, ctypes.POINTER(_vp)]),
+    "vcs_group_create_rank": (ctypes.c_int, [_c_ctx, _vp, ctypes.c_int, ctypes.c_int,
+                                             ctypes.POINTER(_vp)]),
+    "vcs_group_destroy": (ctypes.c_int, [_vp]),
+    "vcs_group_last_error": (ctypes.c_char_p, [_vp]),
+    "vcs_group_info": (ctypes.c_int, [_vp] + [ctypes.POINTER(ctypes.c_int)] * 4),
+    "vcs_group_layout": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "vcs_group_layout_sets": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vcs_group_use_set": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "vcs_group_shard": (ctypes.c_int, [_vp, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 2),
+    "vcs_group_upload": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u8p]),
+    "vcs_group_set_ref": (ctypes.c_int, [_vp, _u8p]),
+    "vcs_group_prefetch_ref": (ctypes.c_int, [_vp]),
+    "vcs_group_encode": (ctypes.c_int, [_vp]),
+    "vcs_group_decode": (ctypes.c_int, [_vp]),
+    "vcs_group_sync": (ctypes.c_int, [_vp]),
+    "vcs_group_get_mv": (ctypes.c_int, [_vp, _i16p, _u32p]),
+    "vcs_group_max_f64": (ctypes.c_int, [_vp, _f64p]),
+    "vcs_group_barrier": (ctypes.c_int, [_vp]),
     "vcs_gop_reserve": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
     "vcs_gop_upload": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _u8p]),
     "vcs_gop_encode": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
@@ -74,6 +100,7 @@ SIGNATURES = {
     "vcs_timing_enable": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
     "vcs_timing_reset": (ctypes.c_int, [_c_ctx]),
     "vcs_timing": (ctypes.c_int, [_c_ctx, _f64p, _u64p, ctypes.c_int]),
+    "vcs_me_cycles": (ctypes.c_int, [_c_ctx, _u64p, ctypes.c_int]),
     "vcs_measure_copy_bw": (ctypes.c_int, [_c_ctx, ctypes.c_size_t, ctypes.c_int, _f64p]),
     "vcs_measure_fill_bw": (ctypes.c_int, [_c_ctx, ctypes.c_size_t, ctypes.c_int, _f64p]),
 }
@@ -235,6 +262,7 @@ class Context:
         self.shape = (self.H, self.W, 3)
         self.coeff_mode = VCS_COEFF_F64
         self.slots = 0
+        self.async_slots = 0
 
     # -- plumbing ----------------------------------------------------------
     def _ck(self, rc):
@@ -378,6 +406,26 @@ class Context:
                                               out.ctypes.data_as(_u8p)))
         return out
 
+    # -- pipelined feeder (next row N3) ----------------------------------------
+    def async_reserve(self, n_slots):
+        self._ck(self._lib.vcs_async_reserve(self._h, int(n_slots)))
+        self.async_slots = int(n_slots)
+
+    def encode_p_async(self, slot, cur):
+        """Enqueue one P frame in `slot`; returns its (not yet filled) ResidentPlanes.  `cur`
+        must stay untouched until wait(slot) when it lives in page-locked memory."""
+        cur = _frame(cur, self.shape, "input frame")
+        h = _vp()
+        self._ck(self._lib.vcs_encode_p_async(self._h, int(slot), cur.ctypes.data_as(_u8p),
+                                              ctypes.byref(h)))
+        return ResidentPlanes(self, h)
+
+    def wait(self, slot):
+        mv = np.empty((self.N, 2), np.int16)
+        ns = ctypes.c_uint32(0)
+        self._ck(self._lib.vcs_wait(self._h, int(slot), mv.ctypes.data_as(_i16p), ctypes.byref(ns)))
+        return mv, ns.value
+
     # -- intra prediction (next row N1) ---------------------------------------
     def _plane(self, a, name):
         a = np.asarray(a)
@@ -494,6 +542,11 @@ class Context:
                                       T_COUNT))
         return ms, n
 
+    def me_cycles(self, reset=True):
+        v = ctypes.c_uint64(0)
+        self._ck(self._lib.vcs_me_cycles(self._h, ctypes.byref(v), int(bool(reset))))
+        return v.value
+
     def measure_copy_bw(self, nbytes=1 << 30, iters=10):
         g = ctypes.c_double(0)
         self._ck(self._lib.vcs_measure_copy_bw(self._h, int(nbytes), int(iters), ctypes.byref(g)))
@@ -503,3 +556,235 @@ class Context:
         g = ctypes.c_double(0)
         self._ck(self._lib.vcs_measure_fill_bw(self._h, int(nbytes), int(iters), ctypes.byref(g)))
         return g.value
+
+
+# ---------------------------------------------------------------------------
+# Multi-GPU GOP encode: RCCL inside libvcs_hip.so (vcs_group_*, vcs_encode_gop)
+# ---------------------------------------------------------------------------
+def shard_frames(n_frames, world, rank):
+    """Contiguous chunk [first, first + count) of `n_frames` P frames for shard `rank`
+    (vcs_shard_frames: sizes differ by at most one, earlier shards take the larger)."""
+    first, count = ctypes.c_int(0), ctypes.c_int(0)
+    rc = load().vcs_shard_frames(int(n_frames), int(world), int(rank), ctypes.byref(first),
+                                 ctypes.byref(count))
+    if rc:
+        raise ValueError("bad shard request")
+    return first.value, count.value
+
+
+def comm_unique_id():
+    """128 opaque bytes from ncclGetUniqueId: rank 0 makes them, every rank of a
+    process-per-GPU job passes the same bytes to Group.from_rank."""
+    buf = ctypes.create_string_buffer(128)
+    lib = load()
+    rc = lib.vcs_comm_unique_id(buf, 128)
+    if rc:
+        raise VcsError(rc, (lib.vcs_group_last_error(None) or b"").decode())
+    return buf.raw
+
+
+TRANSPORTS = {1: "RCCL, overlapped with the neighbouring GOPs' kernels", 2: "RCCL, in sequence with the kernels",
+              3: "same-device copies, overlapped", 4: "same-device copies, in sequence"}
+
+
+class Group:
+    """The P frames of a GOP sharded over several contexts (one per GPU); see
+    include/vcs_hip.h.  Group(contexts): single process.  Group.from_rank(ctx, id, world,
+    rank): one process per GPU."""
+
+    def __init__(self, contexts, _handle=None, _world=None):
+        self._lib = load()
+        self.contexts = list(contexts)
+        self._g = _vp()
+        if _handle is not None:
+            self._g = _handle
+        else:
+            arr = (_c_ctx * len(self.contexts))(*[c._h for c in self.contexts])
+            rc = self._lib.vcs_group_create(arr, len(self.contexts), ctypes.byref(self._g))
+            if rc:
+                self._g = _vp()
+                raise VcsError(rc, (self._lib.vcs_group_last_error(None) or b"").decode())
+        w, r0, nl, tr = (ctypes.c_int(0) for _ in range(4))
+        self._lib.vcs_group_info(self._g, ctypes.byref(w), ctypes.byref(r0), ctypes.byref(nl),
+                                 ctypes.byref(tr))
+        self.world, self.rank0, self.n_local, self.transport = w.value, r0.value, nl.value, tr.value
+        self.N = self.contexts[0].N
+        self.n_p = None
+
+    @classmethod
+    def from_rank(cls, ctx, unique_id, world, rank):
+        lib = load()
+        g = _vp()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        rc = lib.vcs_group_create_rank(ctx._h, buf, int(world), int(rank), ctypes.byref(g))
+        if rc:
+            raise VcsError(rc, (lib.vcs_group_last_error(None) or b"").decode())
+        return cls([ctx], _handle=g)
+
+    def _ck(self, rc):
+        if rc:
+            raise VcsError(rc, (self._lib.vcs_group_last_error(self._g) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g.value:
+            if all(getattr(c, "_h", None) is not None and c._h.value for c in self.contexts):
+                self._lib.vcs_group_destroy(self._g)   # (a destroyed context took the group with it)
+            self._g = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def layout(self, n_p_frames, with_decode=False, sets=1):
+        self._ck(self._lib.vcs_group_layout_sets(self._g, int(n_p_frames), int(bool(with_decode)),
+                                                 int(sets)))
+        self.n_p = int(n_p_frames)
+        self.sets, self.set = int(sets), 0
+        for c in self.contexts:
+            c.slots = max(c.slots, 1)
+
+    def use_set(self, k):
+        self._ck(self._lib.vcs_group_use_set(self._g, int(k)))
+        self.set = int(k)
+
+    def slot_of(self, local_idx, k):
+        """Context slot of P frame `k` (GOP index) on local shard `local_idx`, set in use."""
+        first, count = self.shard(local_idx)
+        if not first <= k < first + count:
+            raise IndexError("P frame %d is not on local shard %d" % (k, local_idx))
+        return self.set * count + k - first
+
+    def shard(self, local_idx=0):
+        f, n = ctypes.c_int(0), ctypes.c_int(0)
+        self._ck(self._lib.vcs_group_shard(self._g, int(local_idx), ctypes.byref(f), ctypes.byref(n)))
+        return f.value, n.value
+
+    def upload(self, first_p, frames):
+        frames = np.asarray(frames)
+        shape = self.contexts[0].shape
+        if frames.dtype != np.uint8 or frames.shape[1:] != shape:
+            raise ValueError("frames must be uint8 of shape (n, %d, %d, 3)" % shape[:2])
+        frames = np.ascontiguousarray(frames)
+        self._ck(self._lib.vcs_group_upload(self._g, int(first_p), frames.shape[0],
+                                            frames.ctypes.data_as(_u8p)))
+
+    def set_ref(self, ref):
+        if self.rank0 != 0:
+            return
+        ref = _frame(ref, self.contexts[0].shape, "reference frame")
+        self._ck(self._lib.vcs_group_set_ref(self._g, ref.ctypes.data_as(_u8p)))
+
+    def prefetch_ref(self):
+        self._ck(self._lib.vcs_group_prefetch_ref(self._g))
+
+    def encode(self):
+        self._ck(self._lib.vcs_group_encode(self._g))
+
+    def decode(self):
+        self._ck(self._lib.vcs_group_decode(self._g))
+
+    def sync(self):
+        self._ck(self._lib.vcs_group_sync(self._g))
+
+    def get_mv(self):
+        mv = np.zeros((self.n_p, self.N, 2), np.int16)
+        ns = np.zeros(self.n_p, np.uint32)
+        self._ck(self._lib.vcs_group_get_mv(self._g, mv.ctypes.data_as(_i16p), ns.ctypes.data_as(_u32p)))
+        return mv, ns
+
+    def max_over_ranks(self, v):
+        x = ctypes.c_double(float(v))
+        self._ck(self._lib.vcs_group_max_f64(self._g, ctypes.byref(x)))
+        return x.value
+
+    def barrier(self):
+        self._ck(self._lib.vcs_group_barrier(self._g))
+
+
+def encode_gop(contexts, frames, want_planes=False):
+    """vcs_encode_gop: frames[0] is the I frame, frames[1:] its P frames.  Returns
+    (mv (n-1, N, 2) int16, planes (n-1, 3, H, W) or None)."""
+    lib = load()
+    c0 = contexts[0]
+    frames = np.asarray(frames)
+    if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[1:] != c0.shape or len(frames) < 1:
+        raise ValueError("frames must be uint8 of shape (n >= 1, %d, %d, 3)" % c0.shape[:2])
+    frames = np.ascontiguousarray(frames)
+    n = frames.shape[0]
+    mv = np.zeros((n - 1, c0.N, 2), np.int16)
+    planes = np.zeros((n - 1, 3, c0.H, c0.W), c0.coeff_dtype) if want_planes else None
+    arr = (_c_ctx * len(contexts))(*[c._h for c in contexts])
+    rc = lib.vcs_encode_gop(arr, len(contexts), frames.ctypes.data_as(_u8p), n,
+                            mv.ctypes.data_as(_i16p),
+                            planes.ctypes.data_as(_vp) if want_planes else None)
+    if rc:
+        raise VcsError(rc, (lib.vcs_group_last_error(None) or b"").decode())
+    return mv, planes
+
+
+def _job_tag():
+    """Names one launch of a process-per-GPU job on this node: the launcher's port and run
+    id, plus -- under torch.distributed.run, whose workers are all children of one agent
+    process -- that agent's pid, so that a file left behind by an earlier (crashed) launch
+    on the same port is never mistaken for this one's.  VCS_RENDEZVOUS_TAG overrides."""
+    t = os.environ.get("VCS_RENDEZVOUS_TAG")
+    if t:
+        return t
+    agent = os.getppid() if "TORCHELASTIC_RUN_ID" in os.environ else 0
+    return "%s_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                            os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), agent)
+
+
+def rendezvous_unique_id(rank, world, timeout_s=180.0, tag=None, make_id=None):
+    """Hands rank 0's RCCL unique id to the other processes of a one-node, process-per-GPU
+    job (torch.distributed.run sets RANK / WORLD_SIZE / MASTER_PORT; nothing of PyTorch is
+    imported).  Rank 0 writes the 128 bytes to a file named after the job in /dev/shm (or
+    $TMPDIR), atomically; the others poll for it.  Files older than the timeout are stale."""
+    import tempfile
+    import time
+    make_id = make_id or comm_unique_id
+    if world == 1:
+        return make_id()
+    tag = tag or _job_tag()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(base, "vcs_hip_rccl_id_%d_%s_w%d" % (os.getuid(), tag, world))
+    if rank == 0:
+        uid = make_id()
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(b"VCSID1" + uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < timeout_s:
+        try:
+            st = os.stat(path)
+            if time.time() - st.st_mtime < timeout_s:
+                blob = open(path, "rb").read()
+                if len(blob) == 6 + 128 and blob[:6] == b"VCSID1":
+                    return blob[6:]
+        except OSError:
+            pass
+        time.sleep(0.05)
+    raise TimeoutError("rank %d: no RCCL unique id from rank 0 at %s" % (rank, path))
+
+
+def rendezvous_cleanup(rank, world, tag=None):
+    """Rank 0 removes the id file once every rank has joined (call after a barrier)."""
+    import tempfile
+    if world == 1 or rank != 0:
+        return
+    tag = tag or _job_tag()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    try:
+        os.unlink(os.path.join(base, "vcs_hip_rccl_id_%d_%s_w%d" % (os.getuid(), tag, world)))
+    except OSError:
+        pass
