@@ -212,6 +212,11 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
       const int by0 = seg * seg_len, by1 = min(by0 + seg_len, g.nby);
       const int x = bxi * BS, j_min = max(x - WIN, 0), j_max = min(x + WIN, g.W);
       const uint8_t *__restrict__ colbase = ref + (size_t)(3 * j_min);  // uniform
+      // candidate columns of this block column (motion.py:137-140) and cand / ncj by
+      // multiplication (cand < 128, ncj <= 10): once per unit, not a division per block
+      const int rj = j_max - BS - j_min;
+      const int ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
+      const uint32_t inv_ncj = ncj ? 65536u / (uint32_t)ncj + 1u : 0u;
 
       int B = max(by0 * BS - WIN, 0);
       int Bslot = B % RING;
@@ -309,8 +314,7 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
         const uint32_t sdiff = s_d >> 1;
         const bool is_static = !g.never_static && sdiff <= g.thresh;
         if (is_static && lane == 0) {
-            mv[2 * oidx + 0] = 0;
-            mv[2 * oidx + 1] = 0;
+            *(uint32_t *)(mv + 2 * oidx) = 0u;
             atomicAdd(&n_static[f], 1u);
             if (cost_out) cost_out[oidx] = sdiff;
         }
@@ -326,14 +330,13 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 
             // ---- candidate grid (motion.py:132-140); i_min = B ---------------------
             const int i_min = B, i_max = min(y + WIN, g.H);
-            const int ri = i_max - BS - i_min, rj = j_max - BS - j_min;
+            const int ri = i_max - BS - i_min;
             const int nci = ri >= 1 ? (ri - 1) / STEP + 1 : 0;
-            const int ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
             const int ncand = nci * ncj;
             const int cand0 = lane, cand1 = lane + 64;
             const bool act0 = cand0 < ncand, act1 = cand1 < ncand;
             int ci0 = 0, cj0 = 0;
-            if (act0) { ci0 = cand0 / ncj; cj0 = cand0 - ci0 * ncj; }
+            if (act0) { ci0 = (int)(((uint32_t)cand0 * inv_ncj) >> 16); cj0 = cand0 - ci0 * ncj; }
             int s0 = Bslot + STEP * ci0;
             s0 -= s0 >= RING ? RING : 0;
 
@@ -362,12 +365,13 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
                 unsigned long long c = 9999999999ull;
                 if (key != 0xFFFFFFFFu) {
                     const int cb = (int)(key & 127u);
-                    byy = i_min + (cb / ncj) * STEP;
-                    bx = j_min + (cb % ncj) * STEP;
+                    const int cbi = (int)(((uint32_t)cb * inv_ncj) >> 16);
+                    byy = i_min + cbi * STEP;
+                    bx = j_min + (cb - cbi * ncj) * STEP;
                     c = key >> 7;
                 }
-                mv[2 * oidx + 0] = (int16_t)(bx - x);
-                mv[2 * oidx + 1] = (int16_t)(byy - y);
+                // one 4-byte store: [dx, dy]
+                *(uint32_t *)(mv + 2 * oidx) = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);
                 if (cost_out) cost_out[oidx] = c;
             }
             wave_lds_fence();  // s_cur / s_part are rewritten by the next block

@@ -1,0 +1,356 @@
+// me_group8.hpp -- k_me8g<W>: the shared rolling window of k_me16g (me_group.hpp) at the
+// reference's OWN default operating point (main.py:15 BLOCK_SIZE = 8: +-16 px window,
+// stride-3 grid; motion.py:18,132).  Same arithmetic as k_me8 (me_fast8.hpp: 3-pixel groups
+// padded to 16-byte LDS slots, cost = sum(r) - sum(c) + 256 * #{r < c}, lane = candidate,
+// 64 candidates = one full wave), same results bit for bit.
+//
+// k_me8 re-fetched and re-parked its whole 32-row window (352 16-byte items, 5.6 KB) for every
+// 8x8 block, although the block below shares 24 of those rows and the same block of 28 other
+// P frames needs exactly the same window: per block it spent 2.3 k cycles of a SIMD on 640
+// cycles of comparisons.  Here a workgroup is W waves = W consecutive P frames walking down
+// one block column (a segment of it) together:
+//   * one window per workgroup, a ring of 40 rows (32 live + the 8 the next block adds) + 7
+//     mirror rows (ring slots 0..6 repeated behind slot 39: a candidate's 8 rows never wrap);
+//   * a block brings in 8 new rows x 11 groups = 88 items for the WHOLE workgroup;
+//   * one LDS-only s_barrier per block (new rows go where the previous block's rows were);
+//   * single-buffered row pipeline (me16g_step's scheme): next row's loads behind the lerps.
+#pragma once
+#include <hip/hip_ext.h>
+
+#include "me_fast8.hpp"
+#include "me_group.hpp"
+
+namespace vcs {
+
+constexpr int kMe8gRing = 40;
+constexpr int kMe8gMirror = 7;
+constexpr int kMe8gWinBytes = (kMe8gRing + kMe8gMirror) * kMe8RowB;
+constexpr int kMe8gWaveBytes = 8 * 48;  // the wave's re-packed current block
+
+struct Me8Q {
+    uint4 q0, q1, q2;
+};
+__device__ __forceinline__ void me8_ld(Me8Q &Q, const void *p) {
+    const uint4 *a = (const uint4 *)p;
+    Q.q0 = a[0]; Q.q1 = a[1]; Q.q2 = a[2];
+}
+
+// one row step: 8 v_lerp_u8, the next row's loads, 8 v_and, 8 v_bcnt (see me16g_step)
+template <bool NEXT>
+__device__ __forceinline__ void me8g_step(Me8Q &a, Me8Q &c, const void *na, const void *nc_,
+                                          uint32_t (&cnt)[2]) {
+    const uint32_t r[8] = {a.q0.x, a.q0.y, a.q0.z, a.q1.x, a.q1.y, a.q1.z, a.q2.x, a.q2.y};
+    const uint32_t nc[8] = {c.q0.x, c.q0.y, c.q0.z, c.q1.x, c.q1.y, c.q1.z, c.q2.x, c.q2.y};
+    asm volatile("" ::"v"(a.q0.w), "v"(a.q1.w), "v"(a.q2.z), "v"(a.q2.w));  // keep whole ds_read_b128s
+    uint32_t t[8];
+#pragma unroll
+    for (int d = 0; d < 8; d++) t[d] = __builtin_amdgcn_lerp(r[d], nc[d], 0x01010101u);
+    __builtin_amdgcn_sched_barrier(0);
+    if (NEXT) {
+        me8_ld(c, nc_);
+        me8_ld(a, na);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < 8; d++) t[d] &= 0x80808080u;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        cnt[d & 1] = (uint32_t)__builtin_popcount(t[d]) + cnt[d & 1];  // v_bcnt_u32_b32 t, cnt
+        asm volatile("" : "+v"(cnt[d & 1]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int W>
+struct Me8gCfg {
+    static constexpr int kLanes = 64 * W;
+    static constexpr int kNewN = (8 * kMe8Groups + kLanes - 1) / kLanes;           // items per lane per roll
+    static constexpr int kFillN = (kMe8Rows * kMe8Groups + kLanes - 1) / kLanes;   // items per lane per fill
+};
+
+template <int W>
+struct Me8gRegs {
+    uint32_t rv, cv, cq, sr;
+    uint4 nw[Me8gCfg<W>::kNewN];
+};
+
+template <int W, int WPS>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
+void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
+            Geom g, int n_frames, int seg_len, const uint32_t *__restrict__ sums,
+            int16_t *__restrict__ mv, uint32_t *__restrict__ n_static,
+            unsigned long long *__restrict__ cost_out) {
+    using Cfg = Me8gCfg<W>;
+    constexpr int ROWB = kMe8RowB, RING = kMe8gRing, NG = kMe8Groups;
+    constexpr int BS = 8, WIN = 16, STEP = 3;
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe8gWinBytes + W * kMe8gWaveBytes];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint8_t *const s_win = s_lds;
+    uint32_t *const s_cur = (uint32_t *)(s_lds + kMe8gWinBytes + wave * kMe8gWaveBytes);
+
+    const int nseg = (g.nby + seg_len - 1) / seg_len;
+    const int ngroups = (n_frames + W - 1) / W;
+    const int per_group = nseg * g.nbx, total = ngroups * per_group;
+    const int nx = 8;
+    const int xcd = blockIdx.x % nx, wi = blockIdx.x / nx, nwg = gridDim.x / nx;
+    const int chunk = (total + nx - 1) / nx;
+    const int u_end = min((xcd + 1) * chunk, total);
+
+    // ---- per-lane offsets, once ---------------------------------------------------
+    const int e0 = min(lane, 47), row0 = e0 / 6, col0 = e0 - row0 * 6;
+    const uint32_t o_blk = (uint32_t)(row0 * g.pitch + 4 * col0);
+    const int crow = lane >> 3, cqq = lane & 7;
+    const int csl = cqq < 3 ? 0 : cqq < 6 ? 1 : 2, cd = cqq - 3 * csl;
+    const uint32_t o_cq = (uint32_t)(crow * g.pitch + 9 * csl + 4 * cd);
+    const uint32_t cur_padm = cd == 2 ? 0xFFFFFF00u : (csl == 2 && cd == 1) ? 0xFFFF0000u : 0u;
+    const int cur_dst = crow * 12 + csl * 4 + cd;
+    uint32_t o_new_src[Cfg::kNewN], o_new_dst[Cfg::kNewN];
+    int o_new_row[Cfg::kNewN];
+#pragma unroll
+    for (int t = 0; t < Cfg::kNewN; t++) {
+        const int e = tid + Cfg::kLanes * t;
+        const int ec = min(e, 8 * NG - 1), row = ec / NG, gi = ec - row * NG;
+        o_new_src[t] = (uint32_t)(row * g.pitch + 9 * gi);
+        o_new_dst[t] = (uint32_t)(row * ROWB + gi * 16);
+        o_new_row[t] = e < 8 * NG ? row : 99;
+    }
+
+    for (int u = xcd * chunk + wi; u < u_end; u += nwg) {
+      const int gi_ = u / per_group, r = u - gi_ * per_group;
+      const int seg = r / g.nbx, bxi = r - seg * g.nbx;
+      const int f = gi_ * W + wave;
+      const bool active = f < n_frames;
+      const int fc = active ? f : n_frames - 1;
+      const int by0 = seg * seg_len, by1 = min(by0 + seg_len, g.nby);
+      const int x = bxi * BS, j_min = max(x - WIN, 0), j_max = min(x + WIN, g.W);
+      const uint8_t *__restrict__ colbase = ref + (size_t)(3 * j_min);
+      // candidate columns of this block column (motion.py:137-140); lane / ncj by multiplication
+      const int rj = j_max - BS - j_min;
+      const int ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
+      const uint32_t inv_ncj = ncj ? 65536u / (uint32_t)ncj + 1u : 0u;
+      const int lci = (int)(((uint32_t)lane * inv_ncj) >> 16), lcj = lane - lci * ncj;  // this lane's candidate
+
+      int B = max(by0 * BS - WIN, 0);
+      int Bslot = B % RING;
+      if (W > 1) wg_lds_barrier();
+      {
+          const uint8_t *__restrict__ wsrc = colbase + (size_t)B * g.pitch;
+          uint4 stg[Cfg::kFillN];
+#pragma unroll
+          for (int q = 0; q < Cfg::kFillN; q++) {
+              const int e = min(tid + Cfg::kLanes * q, kMe8Rows * NG - 1), row = e / NG, gg = e - row * NG;
+              stg[q] = load16_any_align(wsrc + (size_t)row * g.pitch + 9 * gg);
+          }
+#pragma unroll
+          for (int q = 0; q < Cfg::kFillN; q++) {
+              const int e = tid + Cfg::kLanes * q, row = e / NG, gg = e - row * NG;
+              uint4 v = stg[q];
+              v.z &= 0xFFu;  // bytes 9..15 of the slot: pad
+              v.w = 0u;
+              int slot = Bslot + row;
+              slot -= slot >= RING ? RING : 0;
+              if (e < kMe8Rows * NG) {
+                  *(uint4 *)(s_win + slot * ROWB + gg * 16) = v;
+                  if (slot < kMe8gMirror) *(uint4 *)(s_win + (slot + RING) * ROWB + gg * 16) = v;
+              }
+          }
+      }
+
+      auto issue = [&](int byy, int Bwin, Me8gRegs<W> &R) {
+          const size_t blk_off = (size_t)(byy * BS) * g.pitch + (size_t)(24 * bxi);
+          const uint8_t *__restrict__ cblk = curs + (size_t)fc * cur_stride + blk_off;
+          const uint8_t *__restrict__ rblk = ref + blk_off;
+          R.rv = *(const uint32_t *)(rblk + o_blk);
+          R.cv = *(const uint32_t *)(cblk + o_blk);
+          uint32_t v;
+          __builtin_memcpy(&v, cblk + o_cq, 4);
+          R.cq = v;
+          R.sr = sums[(size_t)(byy * g.nbx + bxi) * kMe8SumStride + lane];
+          const uint8_t *__restrict__ nsrc = colbase + (size_t)(Bwin + kMe8Rows) * g.pitch;
+#pragma unroll
+          for (int t = 0; t < Cfg::kNewN; t++) R.nw[t] = load16_any_align(nsrc + o_new_src[t]);
+      };
+
+      Me8gRegs<W> A;
+      issue(by0, B, A);
+
+      for (int by = by0; by < by1; by++) {
+        const int y = by * BS;
+        const bool last = by + 1 == by1;
+        const int byn = last ? by : by + 1;
+        const int Bn = max(byn * BS - WIN, 0);
+        const bool roll = !last && Bn != B;
+        Me8gRegs<W> Bq;
+        issue(byn, Bn, Bq);
+
+        if (W > 1) wg_lds_barrier(); else wave_lds_fence();
+        if (roll) {
+            int ns = Bslot + kMe8Rows;
+            ns -= ns >= RING ? RING : 0;  // a multiple of 8: the 8 rows never wrap
+#pragma unroll
+            for (int q = 0; q < Cfg::kNewN; q++) {
+                uint4 v = A.nw[q];
+                v.z &= 0xFFu;
+                v.w = 0u;
+                if (o_new_row[q] < 8) {
+                    *(uint4 *)(s_win + ns * ROWB + o_new_dst[q]) = v;
+                    if (ns == 0 && o_new_row[q] < kMe8gMirror)
+                        *(uint4 *)(s_win + RING * ROWB + o_new_dst[q]) = v;
+                }
+            }
+        }
+
+        if (active) {
+        const size_t oidx = (size_t)f * g.N + (size_t)(by * g.nbx + bxi);
+        // ---- static test (motion.py:109-116) over the 48 dwords of the block ------
+        uint32_t s_c = 0, s_d = 0;
+        if (lane < 48) {
+            s_d = __builtin_amdgcn_sad_u8(A.rv, A.cv, 0u);
+            s_d = __builtin_amdgcn_sad_u8(A.rv, 0u, s_d);
+            s_c = __builtin_amdgcn_sad_u8(A.cv, 0u, 0u);
+        }
+        s_d = wave_sum_u32(s_d - s_c);
+        s_c = wave_sum_u32(s_c);
+        const uint32_t sdiff = s_d >> 1;
+        const bool is_static = !g.never_static && sdiff <= g.thresh;
+        if (is_static && lane == 0) {
+            *(uint32_t *)(mv + 2 * oidx) = 0u;
+            atomicAdd(&n_static[f], 1u);
+            if (cost_out) cost_out[oidx] = sdiff;
+        }
+        if (!is_static) {
+            s_cur[cur_dst] = ~A.cq | cur_padm;  // negated current block, pad / foreign bytes -> 0xFF
+            wave_lds_fence();
+
+            // ---- candidate grid (motion.py:132-140); i_min = B ---------------------
+            const int i_min = B, i_max = min(y + WIN, g.H);
+            const int ri = i_max - BS - i_min;
+            const int nci = ri >= 1 ? (ri - 1) / STEP + 1 : 0;
+            const int ncand = nci * ncj;  // <= 64
+            const bool act = lane < ncand;
+            const int ci = act ? lci : 0, cj = act ? lcj : 0;
+            int s0 = Bslot + STEP * ci;
+            s0 -= s0 >= RING ? RING : 0;
+            const uint8_t *p = s_win + s0 * ROWB + cj * 16;
+
+            uint32_t cnt[2] = {0, 0};
+            Me8Q a, c;
+            me8_ld(c, s_cur);
+            me8_ld(a, p);
+#pragma unroll
+            for (int k = 0; k < BS - 1; k++)
+                me8g_step<true>(a, c, p + (k + 1) * ROWB, s_cur + (k + 1) * 12, cnt);
+            me8g_step<false>(a, c, nullptr, nullptr, cnt);
+
+            // cost = sum(r) - sum(c) + 256 * #{r < c}; 64 pad bytes always counted
+            const uint32_t n_lt = 192u + 64u - (cnt[0] + cnt[1]);
+            const uint32_t cost = A.sr + 256u * n_lt - s_c;
+            uint32_t key = act ? ((cost << 7) | (uint32_t)lane) : 0xFFFFFFFFu;  // motion.py:149
+            key = wave_min_u32(key);
+            if (lane == 0) {
+                int bx = 0, byy = 0;                    // motion.py:102
+                unsigned long long cc = 9999999999ull;  // motion.py:120
+                if (key != 0xFFFFFFFFu) {
+                    const int cb = (int)(key & 127u);
+                    const int cbi = (int)(((uint32_t)cb * inv_ncj) >> 16);
+                    byy = i_min + cbi * STEP;
+                    bx = j_min + (cb - cbi * ncj) * STEP;
+                    cc = key >> 7;
+                }
+                *(uint32_t *)(mv + 2 * oidx) = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);
+                if (cost_out) cost_out[oidx] = cc;
+            }
+            wave_lds_fence();  // s_cur is rewritten by the next block
+        }
+        }  // active
+        if (Bn != B) {
+            Bslot += BS;
+            Bslot -= Bslot >= RING ? RING : 0;
+        }
+        B = Bn;
+        A = Bq;
+      }
+    }
+}
+
+// VCS_ME8_GROUP: frames per workgroup (1, 2, 4, 8; default 4; 0 = k_me8 only).
+inline int me8g_group() {
+    static const int v = [] {
+        const char *e = getenv("VCS_ME8_GROUP");
+        const int w = e ? atoi(e) : 4;
+        return (w == 0 || w == 1 || w == 2 || w == 4 || w == 8) ? w : 4;
+    }();
+    return v;
+}
+inline int me8g_wps() {
+    static const int v = [] {
+        const char *e = getenv("VCS_ME8_WPS");
+        const int w = e ? atoi(e) : 4;
+        return (w >= 2 && w <= 6) ? w : 4;
+    }();
+    return v;
+}
+inline int me8g_seg_len(int nby) {
+    static const int forced = [] {
+        const char *e = getenv("VCS_ME8G_SEG");
+        const int s = e ? atoi(e) : 0;
+        return s >= 1 && s <= 4096 ? s : 0;
+    }();
+    if (forced) return forced;
+    const int nseg = nby <= 34 ? 1 : (nby + 17) / 34;
+    return (nby + nseg - 1) / nseg;
+}
+inline bool me8g_worthwhile(const Geom &g, int cus, int n) {
+    const int w = me8g_group();
+    if (w == 0) return false;
+    if (me16r_mode() == 2) return true;  // VCS_ME16_ROLL=2: tests force the rolling kernels
+    if (me16r_mode() == 0) return false;
+    const int seg = me8g_seg_len(g.nby);
+    const long long units = (long long)((n + w - 1) / w) * ((g.nby + seg - 1) / seg) * g.nbx;
+    const int per_cu = 4 * me8g_wps() / w > 0 ? 4 * me8g_wps() / w : 1;
+    return units * 2 >= (long long)cus * per_cu * 3 && n >= w;
+}
+
+template <int W, int WPS>
+inline int launch_me_group8_t(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
+                              const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
+                              uint32_t *ns, unsigned long long *cost, hipEvent_t ev_start,
+                              hipEvent_t ev_stop) {
+    const int seg = me8g_seg_len(g.nby);
+    const long long units = (long long)((n + W - 1) / W) * ((g.nby + seg - 1) / seg) * g.nbx;
+    static const int per_cu_env = [] {
+        const char *e = getenv("VCS_ME8G_WG_PER_CU");
+        return e ? atoi(e) : 0;
+    }();
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (4 * WPS / W > 0 ? 4 * WPS / W : 1);
+    long long grid = (long long)cus * per_cu;
+    grid = (grid + 7) / 8 * 8;
+    const long long cap = (units + 7) / 8 * 8;
+    dim3 gd((unsigned)(grid > cap ? cap : grid)), block(64 * W);
+    hipExtLaunchKernelGGL((k_me8g<W, WPS>), gd, block, 0, stream, ev_start, ev_stop, 0, ref, curs,
+                          stride, g, n, seg, (const uint32_t *)sums, mv, ns, cost);
+    return 0;
+}
+
+inline int launch_me_group8(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
+                            const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
+                            uint32_t *ns, unsigned long long *cost, hipEvent_t ev_start = nullptr,
+                            hipEvent_t ev_stop = nullptr) {
+    if ((long long)g.N * n > 0x7FFFFFFF) return -1;
+#define VCS_ME8G(Wv, Pv)                                                                           \
+    return launch_me_group8_t<Wv, Pv>(g, stream, cus, ref, curs, stride, n, sums, mv, ns, cost,    \
+                                      ev_start, ev_stop)
+    const int w = me8g_group(), p = me8g_wps();
+    if (w == 1) { if (p <= 3) VCS_ME8G(1, 3); if (p >= 6) VCS_ME8G(1, 6); VCS_ME8G(1, 4); }
+    if (w == 2) { if (p <= 3) VCS_ME8G(2, 3); if (p >= 6) VCS_ME8G(2, 6); VCS_ME8G(2, 4); }
+    if (w == 8) { if (p <= 3) VCS_ME8G(8, 2); if (p >= 6) VCS_ME8G(8, 6); VCS_ME8G(8, 4); }
+    if (p <= 3) VCS_ME8G(4, 3);
+    if (p >= 6) VCS_ME8G(4, 6);
+    if (p == 5) VCS_ME8G(4, 5);
+    VCS_ME8G(4, 4);
+#undef VCS_ME8G
+}
+
+}  // namespace vcs

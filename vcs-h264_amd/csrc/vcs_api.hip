@@ -20,6 +20,7 @@
 #include "me_fast8.hpp"
 #include "me_roll.hpp"
 #include "me_group.hpp"
+#include "me_group8.hpp"
 #include "me_kernels.hpp"
 
 using namespace vcs;
@@ -247,8 +248,9 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         c->sums_valid = true;
     }
     const bool fast16 = c->me_fast_ok && !force_generic;
+    const bool group8 = c->me_fast8_ok && !force_generic && me8g_worthwhile(c->g, c->cus, n);
     EvPair ev;
-    int rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/fast16);  // k_me16r / k_me16: the kernel alone
+    int rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/fast16 || group8);  // the search kernel alone
     if (rc) return rc;
     if (roll) launch_me_roll_primer(c->stream, c->cus, ns, n);
     if (fast16) {
@@ -259,6 +261,9 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
                                           ns, cost, ev.a, ev.b))
                   : launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost,
                                    ev.a, ev.b);
+        if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
+    } else if (group8) {
+        rc = launch_me_group8(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost, ev.a, ev.b);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
     } else if (c->me_fast8_ok && !force_generic) {
         rc = launch_me_fast8(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
