@@ -94,6 +94,17 @@ int vcs_ctx_destroy(vcs_ctx *ctx);
 #define VCS_KEEP_THRESH INT64_MIN
 int vcs_set_params(vcs_ctx *ctx, int win, int step, int64_t sim_thresh,
                    const double *Q3x64, int coeff_mode);
+/* Searches and costs that are NOT in the reference (default: the reference's
+ * own, and only those run on the specialised kernels).  VCS_SEARCH_TSS: the classic three-
+ * step / logarithmic search from the co-located position (steps 16, 8, 4, 2, 1 for +-32;
+ * a stage moves to the cheapest valid neighbour only if it is strictly cheaper than the
+ * centre, ties between neighbours in raster order).  VCS_COST_SAD: sum |r - c| instead of
+ * the reference's wrap-around sum (motion.py:146).  The static early-out is unchanged.  No
+ * reference output exists for these modes (parity unpinned; oracle: vcso_me_ext).  VCS_KEEP
+ * keeps a selector.                                                                       */
+enum { VCS_SEARCH_GRID = 0, VCS_SEARCH_TSS = 1 };
+enum { VCS_COST_WRAP = 0, VCS_COST_SAD = 1 };
+int vcs_set_search(vcs_ctx *ctx, int search, int cost);
 /* Fills Q3x64 by the reference's QF rule (DCTcompressor.py:29-38).          */
 int vcs_make_q(double qf, double *Q3x64);
 /* The 8x8 DCT-II matrix of DCTcompressor.py:124-133, as the kernels use it. */

@@ -309,10 +309,50 @@ def g7_intra_small():
     save("intra_small.npz", **d)
 
 
+def g8_intramodes_small():
+    """The fifteen predictors of the reference's intramodes.py (:7-179), called one by one on
+    recorded neighbour vectors (uint8, as intraframe.py hands them over): 40 random cases plus
+    the extremes that exercise the uint8 wrap of `u + l` and `3 * x // 4`."""
+    import warnings
+    idir = os.path.join(REF, "IntraframeCompression")
+    if idir not in sys.path:
+        sys.path.insert(0, idir)
+    import intramodes as ref_im
+    assert ref_im.__file__.startswith(REF)
+    rng = np.random.default_rng(23)
+    n = 44
+    u = rng.integers(0, 256, (n, 4), dtype=np.uint8)
+    ur = rng.integers(0, 256, (n, 4), dtype=np.uint8)
+    le = rng.integers(0, 256, (n, 4), dtype=np.uint8)
+    ul = rng.integers(0, 256, n, dtype=np.uint8)
+    u16 = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    l16 = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    u8 = rng.integers(0, 256, (n, 8), dtype=np.uint8)
+    l8 = rng.integers(0, 256, (n, 8), dtype=np.uint8)
+    for arr in (u, ur, le, u16, l16, u8, l8):
+        arr[40], arr[41], arr[42], arr[43] = 255, 0, 86, 171
+    ul[40:44] = (255, 0, 86, 171)
+    d = dict(u=u, ur=ur, l=le, ul=ul, u16=u16, l16=l16, u8=u8, l8=l8)
+    calls = {"vertical4x4": lambda k: (u[k],), "horizontal4x4": lambda k: (le[k],),
+             "dc4x4": lambda k: (u[k], le[k]), "downleft4x4": lambda k: (u[k], ur[k]),
+             "downright4x4": lambda k: (ul[k], u[k], le[k]),
+             "verticalright4x4": lambda k: (ul[k], u[k], le[k]),
+             "horizontaldown4x4": lambda k: (ul[k], u[k], le[k]),
+             "verticalleft4x4": lambda k: (u[k], ur[k]), "horizontalup4x4": lambda k: (le[k],),
+             "vertical16x16": lambda k: (u16[k],), "horizontal16x16": lambda k: (l16[k],),
+             "dc16x16": lambda k: (u16[k], l16[k]), "vertical8x8": lambda k: (u8[k],),
+             "horizontal8x8": lambda k: (l8[k],), "dc8x8": lambda k: (u8[k], l8[k])}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, args in calls.items():
+            d["out_" + name] = np.stack([getattr(ref_im, name)(*args(k)) for k in range(n)])
+    save("intramodes_small.npz", **d)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for fn in (g1_me_small, g2_me_edges, g4_dct_small, g5_codec_small, g6_real_small,
-               g7_intra_small, g3_me_1080p):
+               g7_intra_small, g8_intramodes_small, g3_me_1080p):
         if only and fn.__name__.split("_")[0] not in only:
             continue
         print(fn.__name__)

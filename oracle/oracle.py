@@ -84,6 +84,26 @@ def me(cur, ref, bs, win=None, step=None, thresh=2000, want_cost=False):
     return (mv, ns.value, cost) if want_cost else (mv, ns.value)
 
 
+def me_ext(cur, ref, bs, search="grid", cost="wrap", win=None, step=None, thresh=2000,
+           want_cost=False):
+    """Extension searches (not in the reference; parity unpinned): vcso_me_ext."""
+    cur, ref = _c(cur, np.uint8), _c(ref, np.uint8)
+    H, W = cur.shape[:2]
+    win = 2 * bs if win is None else win
+    step = default_step(bs) if step is None else step
+    N = num_blocks(H, W, bs)
+    mv = np.zeros((N, 2), np.int16)
+    ns = ctypes.c_uint32(0)
+    co = np.zeros(N, np.uint64)
+    rc = lib().vcso_me_ext(_p(cur, _u8p), _p(ref, _u8p), H, W, bs, win, step,
+                           ctypes.c_uint32(max(0, min(int(thresh), 0xFFFFFFFF))),
+                           {"grid": 0, "tss": 1}[search], {"wrap": 0, "sad": 1}[cost],
+                           _p(mv, _i16p), ctypes.byref(ns), _p(co, _u64p))
+    if rc:
+        raise ValueError("vcso_me_ext failed")
+    return (mv, ns.value, co) if want_cost else (mv, ns.value)
+
+
 def mc(ref, mv, bs, coords=None):
     """motion.py:42-69."""
     ref = _c(ref, np.uint8)

@@ -135,6 +135,93 @@ int vcso_me(const uint8_t *cur, const uint8_t *ref, int H, int W, int bs,
     return 0;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Extension searches -- NOT in the reference, parity unpinned: this is the
+ * definition the HIP kernel k_me_ext (csrc/me_ext.hpp) is checked against.
+ *   search 0 = the reference's grid (motion.py:132-140), 1 = three-step search:
+ *     centre = the co-located position; S = largest power of two with 2S - 1 <= win; per
+ *     stage the 8 neighbours (dy, dx) in raster order at distance S that keep the block inside
+ *     the frame; move to the cheapest if STRICTLY cheaper than the centre (first wins ties);
+ *     S /= 2 down to 1.
+ *   cost 0 = sum (r - c) mod 256 (motion.py:146), 1 = sum |r - c|.
+ * Static early-out as in find_match.                                                     */
+static uint64_t block_cost(const uint8_t *cur, const uint8_t *ref, size_t pitch, int bs, int x,
+                           int y, int j, int i, int cost_kind) {
+    uint64_t d = 0;
+    for (int r = 0; r < bs; r++) {
+        const uint8_t *pr = ref + (size_t)(i + r) * pitch + (size_t)j * CH;
+        const uint8_t *pc = cur + (size_t)(y + r) * pitch + (size_t)x * CH;
+        for (int b = 0; b < bs * CH; b++)
+            d += cost_kind ? (uint64_t)(pr[b] > pc[b] ? pr[b] - pc[b] : pc[b] - pr[b])
+                           : (uint64_t)(uint8_t)(pr[b] - pc[b]);
+    }
+    return d;
+}
+
+int vcso_me_ext(const uint8_t *cur, const uint8_t *ref, int H, int W, int bs, int win, int step,
+                uint32_t thresh, int search, int cost_kind, int16_t *mv, uint32_t *n_static,
+                uint64_t *cost_out) {
+    int nby, nbx;
+    int N = vcso_num_blocks(H, W, bs, &nby, &nbx);
+    if (step <= 0 || bs <= 0 || win < 1) return -1;
+    const size_t pitch = (size_t)W * CH;
+    uint32_t ns = 0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : ns)
+    for (int k = 0; k < N; k++) {
+        const int x = (k % nbx) * bs, y = (k / nbx) * bs;
+        uint64_t diff = 0;
+        for (int r = 0; r < bs; r++) {
+            const uint8_t *pr = ref + (size_t)(y + r) * pitch + (size_t)x * CH;
+            const uint8_t *pc = cur + (size_t)(y + r) * pitch + (size_t)x * CH;
+            for (int b = 0; b < bs * CH; b++) diff += pr[b] > pc[b] ? (uint64_t)(pr[b] - pc[b]) : 0;
+        }
+        int bx = 0, by = 0;
+        uint64_t best = 9999999999ULL;
+        if (diff <= thresh) {
+            ns++;
+            bx = x; by = y; best = diff;
+        } else if (search == 0) {
+            int i_min = y - win > 0 ? y - win : 0, j_min = x - win > 0 ? x - win : 0;
+            int i_max = y + win < H ? y + win : H, j_max = x + win < W ? x + win : W;
+            for (int i = i_min; i < i_max; i += step) {
+                if (i + bs >= i_max) continue;
+                for (int j = j_min; j < j_max; j += step) {
+                    if (j + bs >= j_max) continue;
+                    uint64_t d = block_cost(cur, ref, pitch, bs, x, y, j, i, cost_kind);
+                    if (d < best) { best = d; bx = j; by = i; }
+                }
+            }
+        } else {
+            int ci = y, cj = x, S = 1;
+            best = block_cost(cur, ref, pitch, bs, x, y, cj, ci, cost_kind);
+            while (2 * (2 * S) - 1 <= win) S *= 2;
+            /* the kernel parks rows / columns [pos - win, pos + win + bs): same validity here */
+            const int lo_i = y - win > 0 ? y - win : 0, lo_j = x - win > 0 ? x - win : 0;
+            const int hi_i = (y + win + bs < H ? y + win + bs : H) - bs;
+            const int hi_j = (x + win + bs < W ? x + win + bs : W) - bs;
+            for (; S >= 1; S >>= 1) {
+                uint64_t sb = ~0ULL;
+                int si = 0, sj = 0;
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (!dy && !dx) continue;
+                        const int i = ci + dy * S, j = cj + dx * S;
+                        if (i < lo_i || i > hi_i || j < lo_j || j > hi_j) continue;
+                        uint64_t d = block_cost(cur, ref, pitch, bs, x, y, j, i, cost_kind);
+                        if (d < sb) { sb = d; si = i; sj = j; }
+                    }
+                if (sb != ~0ULL && sb < best) { best = sb; ci = si; cj = sj; }
+            }
+            bx = cj; by = ci;
+        }
+        mv[2 * k + 0] = (int16_t)(bx - x);
+        mv[2 * k + 1] = (int16_t)(by - y);
+        if (cost_out) cost_out[k] = best;
+    }
+    if (n_static) *n_static = ns;
+    return 0;
+}
+
 /* motion.py:42-69 (reconstruct_from_motion_vectors).  coords nullable =
  * raster grid.  Output zero outside the blocks (:45-46).                    */
 int vcso_mc(const uint8_t *ref, const int16_t *mv, const int32_t *coords,

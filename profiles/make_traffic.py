@@ -2,7 +2,7 @@
 """profiles/<tag>/pmc_per_dispatch.json (written by profiles/collect.sh) -> profiles/hbm_traffic.json,
 the per-launch HBM byte counts bench.py reports as roofline.traffic.
 
-usage: python profiles/make_traffic.py profiles/r01/pmc_per_dispatch.json
+usage: python profiles/make_traffic.py profiles/r02/pmc_per_dispatch.json
 FETCH_SIZE / WRITE_SIZE are in KB per dispatch; FETCH_SIZE is doubled (gfx950 correction,
 MI355X_MICROARCH.md HBM section: 64 B counted per 128-B request for wide coalesced reads).
 """
@@ -14,11 +14,11 @@ H, W, FRAMES, BS = 1080, 1920, 29, 16
 F = H * W * 3
 N = (H // BS) * (W // BS)
 ALG = {  # algorithmic bytes per launch (29 P frames)
-    "k_me16r": FRAMES * (2 * F + 4 * N),
+    "k_me16g": FRAMES * (2 * F + 4 * N),
     "k_fdct<residual>": FRAMES * (10 * F + 4 * N),
     "k_me16_sums": F + N * 128 * 4,
 }
-PMC_PREFIX = {"vcs::k_me16r": "k_me16r", "vcs::k_fdct<1, 0,": "k_fdct<residual>",
+PMC_PREFIX = {"vcs::k_me16g": "k_me16g", "vcs::k_fdct<1, 0,": "k_fdct<residual>",
               "vcs::k_me16_sums": "k_me16_sums"}   # kernel-name prefixes in the PMC summary
 
 
@@ -30,7 +30,7 @@ def main(path):
         if len(keys) != 1:
             sys.exit("expected one kernel starting with %r, found %r" % (prefix, keys))
         v = pmc[keys[0]]
-        if name == "k_me16r":
+        if name == "k_me16g":
             sampled = int(v["dispatches_sampled"])
         fetch, write = int(v["FETCH_SIZE"] * 1024), int(v["WRITE_SIZE"] * 1024)
         corrected = 2 * fetch + write
@@ -41,11 +41,14 @@ def main(path):
             "algorithmic_bytes": ALG[name],
             "ratio_corrected_over_algorithmic": round(corrected / ALG[name], 3),
             "valu_wave_insts_per_dispatch": int(v.get("SQ_INSTS_VALU", 0)),
+            "lds_array_cycles_per_dispatch": int(v.get("SQ_LDS_IDX_ACTIVE", 0)),
+            "grbm_gui_active_per_dispatch": int(v.get("GRBM_GUI_ACTIVE", 0)),
         }
     out = {
         "workload": {"H": H, "W": W, "frames_per_launch": FRAMES, "me_bs": BS},
         "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of "
-               "`bench.py --steps 10 --warmup 2` (profiles/collect.sh); KB per dispatch averaged over "
+               "`bench.py --steps 10 --warmup 2` (profiles/collect.sh; the bench rotates through three resident copies of the GOP, "
+               "so nothing is re-read from the Infinity Cache); KB per dispatch averaged over "
                "%d dispatches.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B "
                "per 128-B request for wide coalesced reads, so it is doubled; WRITE_SIZE is exact "
                "(k_fdct: 29 x 3 x 1080 x 1920 x 8 B = 1,443,225,600 B).  Calibration in our own access "
@@ -54,7 +57,9 @@ def main(path):
                "under-count applies to this pattern too.  k_fdct's 4-byte-per-lane "
                "pixel loads are uncalibrated: its read figure is an upper bound.  k_fdct's traffic is "
                "below its algorithmic bytes because the latter charge the reference frame once per P "
-               "frame (SURVEY 8d) while the band-per-XCD strip mapping keeps it in L2."
+               "frame (SURVEY 8d) while the band-per-XCD strip mapping keeps it in L2.  k_me16g's WRITE_SIZE "
+               "is mostly its scratch backing store (30 spilled registers of the 128-VGPR build, written "
+               "once per wave in the prologue), not results: the vectors are 0.93 MB per launch."
                % sampled,
         "source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)) + "/.."),
         "kernels": kernels,

@@ -218,3 +218,59 @@ def test_resident_planes_outlive_their_context(vh, oracle):
     c.close()
     planes.release()                                        # no error, no leak
     assert planes._h is None
+
+
+# ------------------------------------------------------- extension searches (N4) ----
+@pytest.mark.parametrize("search,cost", [("grid", "sad"), ("tss", "wrap"), ("tss", "sad")])
+def test_extension_searches_vs_oracle(vh, oracle, search, cost, capsys):
+    """vcs_set_search: three-step search and true-SAD cost (NOT in the reference; the oracle is
+    oracle/vcs_oracle.c: vcso_me_ext -- parity unpinned).  Vectors, static counts and winning
+    costs, over block sizes, ragged frames, frame edges, window overrides; the reference's own
+    mode is untouched by a round trip through the extension."""
+    from synth import synth_static, synth_v1
+    cases = [(144, 176, 16, None), (136, 200, 8, None), (50, 70, 4, None), (64, 64, 16, None),
+             (96, 128, 16, 7), (72, 88, 8, 31), (40, 56, 6, None)]
+    for H, W, bs, win in cases:
+        ref, cur = synth_v1(H, W, seed=H + bs, shift=(5, -9))
+        with vh.Context(H, W, bs) as c:
+            c.set_ref(ref)
+            if win:
+                c.set_params(win=win)
+            c.set_search(search, cost)
+            mv, ns, co = c.me(cur, want_cost=True)
+            omv, ons, oco = oracle.me_ext(cur, ref, bs, search, cost, win=win, want_cost=True)
+            assert np.array_equal(mv, omv) and ns == ons, (H, W, bs, win)
+            assert np.array_equal(co, oco), (H, W, bs, win)
+            # the fused encode path uses the same vectors
+            if H % 8 == 0 and W % 8 == 0:
+                mv2, planes, _, _ = c.encode_p(cur)
+                assert np.array_equal(mv2, omv)
+            c.set_search("grid", "wrap")       # back to the reference's search
+            mv, ns = c.me(cur)
+            omv, ons = oracle.me(cur, ref, bs, win=win)
+            assert np.array_equal(mv, omv) and ns == ons
+    # static-heavy content and a full 1080p frame
+    ref, cur = synth_static(1080, 1920, seed=2, bs=16, frac=0.5)
+    with vh.Context(1080, 1920, 16) as c:
+        c.set_ref(ref)
+        c.set_search(search, cost)
+        mv, ns = c.me(cur)
+        omv, ons = oracle.me_ext(cur, ref, 16, search, cost)
+        assert np.array_equal(mv, omv) and ns == ons and ns > 0
+    # through the drop-in class: module constants, as the reference's other knobs
+    import motion as M
+    from _runtime import release_contexts
+    release_contexts()
+    ref, cur = synth_v1(144, 176, seed=3, shift=(7, -11))
+    M.SEARCH, M.COST = search, cost
+    try:
+        mv, _ = M.MotionProcessor(16, [144, 176]).process_motion_prediction(cur, ref)
+        assert np.array_equal(np.array(mv), oracle.me_ext(cur, ref, 16, search, cost)[0])
+    finally:
+        M.SEARCH, M.COST = "grid", "wrap"
+        release_contexts()
+    if search == "tss" and cost == "sad":
+        # what the extension is for: it finds the true displacement of a globally shifted frame
+        dx_dy = np.array(mv)[(144 // 16 // 2) * (176 // 16) + 5]
+        assert dx_dy.tolist() == [11, -7]
+    capsys.readouterr()

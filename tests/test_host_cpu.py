@@ -207,3 +207,33 @@ def test_reference_structured_loop_equals_the_oracle():
     for ch in range(3):
         got = ref_loop.compress_plane(ycc[..., ch].astype(np.int16) - 128, Q[ch])
         assert np.max(np.abs(got - planes[ch])) < 1e-9   # NumPy's matmul order, not the oracle's fma chain
+
+
+def test_intramodes_dropin_matches_the_reference_functions():
+    """IntraframeCompression/intramodes.py (the fifteen predictors as importable functions,
+    intraframe.py:7 upstream does `from intramodes import *`) against outputs of the
+    reference's own functions on recorded inputs (oracle/gen_golden.py: g8)."""
+    import importlib.util
+    import warnings
+    spec = importlib.util.spec_from_file_location(
+        "dropin_intramodes", os.path.join(REPO, "vcs-h264_amd", "IntraframeCompression", "intramodes.py"))
+    im = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(im)
+    g = load_golden("intramodes_small.npz")
+    u, ur, le, ul = g["u"], g["ur"], g["l"], g["ul"]
+    args = {"vertical4x4": lambda k: (u[k],), "horizontal4x4": lambda k: (le[k],),
+            "dc4x4": lambda k: (u[k], le[k]), "downleft4x4": lambda k: (u[k], ur[k]),
+            "downright4x4": lambda k: (ul[k], u[k], le[k]), "verticalright4x4": lambda k: (ul[k], u[k], le[k]),
+            "horizontaldown4x4": lambda k: (ul[k], u[k], le[k]), "verticalleft4x4": lambda k: (u[k], ur[k]),
+            "horizontalup4x4": lambda k: (le[k],), "vertical16x16": lambda k: (g["u16"][k],),
+            "horizontal16x16": lambda k: (g["l16"][k],), "dc16x16": lambda k: (g["u16"][k], g["l16"][k]),
+            "vertical8x8": lambda k: (g["u8"][k],), "horizontal8x8": lambda k: (g["l8"][k],),
+            "dc8x8": lambda k: (g["u8"][k], g["l8"][k])}
+    assert len(args) == 15
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")   # NumPy's uint8 scalar overflow warnings, as upstream
+        for name, a in args.items():
+            want = g["out_" + name]
+            for k in range(len(u)):
+                got = getattr(im, name)(*a(k))
+                assert got.dtype == np.float64 and np.array_equal(got, want[k]), (name, k)

@@ -13,6 +13,11 @@ from _runtime import ensure_ref, get_context
 SIMILARITY_THRESHOLD = 2000
 CHANNELS = 3
 WRITE_STATIC_BLOCK = True
+# Extensions, NOT in the reference (defaults = the reference's behaviour):
+# SEARCH "grid" (motion.py:132-140) or "tss" (three-step search), COST "wrap" (the uint8
+# wrap-around sum of motion.py:146) or "sad" (sum |r - c|).  Edit like the constants above.
+SEARCH = "grid"
+COST = "wrap"
 
 
 def _as_frame(a, shape, what):
@@ -39,9 +44,10 @@ class MotionProcessor:
         ctx = get_context(self.shape[0], self.shape[1], self.block_size, self.device)
         # module constants / attributes may have been edited by hand, as the
         # reference expects (SURVEY.md section 5 "config / flags")
-        params = (self.search_window_size, round(self.block_size / 3), SIMILARITY_THRESHOLD)
+        params = (self.search_window_size, round(self.block_size / 3), SIMILARITY_THRESHOLD, SEARCH, COST)
         if getattr(ctx, "_me_params", None) != params:
             ctx.set_params(win=params[0], step=params[1], sim_thresh=params[2])
+            ctx.set_search(SEARCH, COST)
             ctx._me_params = params
         return ctx
 

@@ -22,6 +22,7 @@
 #include "me_group.hpp"
 #include "me_group8.hpp"
 #include "me_kernels.hpp"
+#include "me_ext.hpp"
 
 using namespace vcs;
 
@@ -53,6 +54,7 @@ struct vcs_ctx {
     Geom g{};
     int64_t thresh64 = 2000;
     int coeff_mode = VCS_COEFF_F64;
+    int search = VCS_SEARCH_GRID, cost = VCS_COST_WRAP;  // vcs_set_search (extensions)
     size_t F = 0, Fs = 0;  // frame bytes, padded frame stride
     size_t me_lds = 0;     // dynamic LDS of the generic ME kernel
     bool ref_valid = false;
@@ -143,10 +145,12 @@ int py_round_div3(int bs) {  // Python round(bs / 3): half to even (motion.py:13
 }
 
 // LDS demand of k_me_generic for the current geometry; 0 if it cannot fit.
-size_t me_generic_lds(const Geom &g, int *wpitch_out) {
+size_t me_generic_lds(const Geom &g, int *wpitch_out, int ext = 0) {
+    // ext: extra rows / columns behind the reference's window (the three-step search of
+    // me_ext.hpp parks y - win .. y + win + bs)
     const int rowb = 3 * g.bs, cpitch = (rowb + 3) & ~3;
-    const int wpitch = ((3 * 2 * g.win + 3 + 3) & ~3) + 8;
-    size_t lds = round_up((size_t)g.bs * cpitch, 16) + (size_t)2 * g.win * wpitch + 16;
+    const int wpitch = ((3 * (2 * g.win + ext) + 3 + 3) & ~3) + 8;
+    size_t lds = round_up((size_t)g.bs * cpitch, 16) + (size_t)(2 * g.win + ext) * wpitch + 16;
     if (wpitch_out) *wpitch_out = wpitch;
     return lds;
 }
@@ -154,7 +158,7 @@ size_t me_generic_lds(const Geom &g, int *wpitch_out) {
 int refresh_me_geometry(vcs_ctx *c) {
     Geom &g = c->g;
     if (g.win < 1 || g.step < 1) return fail(c, VCS_E_ARG, "win and step must be >= 1");
-    size_t lds = me_generic_lds(g, &g.wpitch);
+    size_t lds = me_generic_lds(g, &g.wpitch, c->search == VCS_SEARCH_TSS ? g.bs : 0);
     if (lds > 160 * 1024)
         return fail(c, VCS_E_ARG, "search window (bs=%d win=%d) needs %zu B of LDS, > 160 KiB",
                     g.bs, g.win, lds);
@@ -164,8 +168,9 @@ int refresh_me_geometry(vcs_ctx *c) {
     g.never_static = c->thresh64 < 0;
     // VCS_ME_GENERIC=1 forces the generic kernel (A/B measurements, debugging)
     const char *force = getenv("VCS_ME_GENERIC");
-    c->me_fast_ok = me_fast_supported(g) && !(force && force[0] == '1');
-    c->me_fast8_ok = me_fast8_supported(g) && !(force && force[0] == '1');
+    const bool reference_search = c->search == VCS_SEARCH_GRID && c->cost == VCS_COST_WRAP;
+    c->me_fast_ok = reference_search && me_fast_supported(g) && !(force && force[0] == '1');
+    c->me_fast8_ok = reference_search && me_fast8_supported(g) && !(force && force[0] == '1');
     return VCS_OK;
 }
 
@@ -268,6 +273,20 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     } else if (c->me_fast8_ok && !force_generic) {
         rc = launch_me_fast8(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
+    } else if (c->search != VCS_SEARCH_GRID || c->cost != VCS_COST_WRAP) {
+        if (c->me_lds > 48 * 1024) {
+#define VCS_EXT_ATTR(S, C)                                                                      \
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k_me_ext<S, C>,                                \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->me_lds))
+            VCS_EXT_ATTR(kSearchGrid, kCostSad); VCS_EXT_ATTR(kSearchTss, kCostWrap); VCS_EXT_ATTR(kSearchTss, kCostSad);
+#undef VCS_EXT_ATTR
+        }
+#define VCS_EXT(S, C)                                                                           \
+    hipLaunchKernelGGL((k_me_ext<S, C>), dim3(c->g.N, n), dim3(64), c->me_lds, c->stream, ref, curs, \
+                       stride, c->g, mv, ns, cost)
+        if (c->search == VCS_SEARCH_TSS) { if (c->cost == VCS_COST_SAD) VCS_EXT(kSearchTss, kCostSad); else VCS_EXT(kSearchTss, kCostWrap); }
+        else VCS_EXT(kSearchGrid, kCostSad);
+#undef VCS_EXT
     } else {
         switch (c->g.bs) {
             case 16: rc = launch_me_generic_t<16>(c, ref, curs, stride, n, mv, ns, cost); break;
@@ -739,6 +758,25 @@ int vcs_set_params(vcs_ctx *c, int win, int step, int64_t sim_thresh, const doub
         HIP_TRY(c, hipMemcpy(c->d_DQ, c->hDQ, sizeof(double) * 448, hipMemcpyHostToDevice));
     }
     return VCS_OK;
+}
+
+int vcs_set_search(vcs_ctx *c, int search, int cost) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (search == VCS_KEEP) search = c->search;
+    if (cost == VCS_KEEP) cost = c->cost;
+    if (search < VCS_SEARCH_GRID || search > VCS_SEARCH_TSS || cost < VCS_COST_WRAP || cost > VCS_COST_SAD)
+        return fail(c, VCS_E_ARG, "bad search / cost selector (%d, %d)", search, cost);
+    const int s0 = c->search, c0 = c->cost;
+    c->search = search;
+    c->cost = cost;
+    rc = refresh_me_geometry(c);
+    if (rc) {
+        c->search = s0;
+        c->cost = c0;
+        refresh_me_geometry(c);
+    }
+    return rc;
 }
 
 int vcs_set_ref(vcs_ctx *c, const uint8_t *ref) {

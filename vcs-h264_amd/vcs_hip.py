@@ -38,6 +38,7 @@ SIGNATURES = {
     "vcs_ctx_destroy": (ctypes.c_int, [_c_ctx]),
     "vcs_set_params": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_int64, _f64p,
                                       ctypes.c_int]),
+    "vcs_set_search": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
     "vcs_make_q": (ctypes.c_int, [ctypes.c_double, _f64p]),
     "vcs_dct_matrix": (ctypes.c_int, [_f64p]),
     "vcs_set_ref": (ctypes.c_int, [_c_ctx, _u8p]),
@@ -302,6 +303,13 @@ class Context:
             qp = Q.ctypes.data_as(_f64p)
         self._ck(self._lib.vcs_set_params(self._h, int(win), int(step), int(sim_thresh), qp, cm))
         self.coeff_mode = cm
+
+    def set_search(self, search="grid", cost="wrap"):
+        """Extensions (not in the reference): search "grid" (reference) / "tss" (three-step),
+        cost "wrap" (reference) / "sad"; None keeps a selector."""
+        sv = {None: -1, "grid": 0, "tss": 1}[search]
+        cv = {None: -1, "wrap": 0, "sad": 1}[cost]
+        self._ck(self._lib.vcs_set_search(self._h, sv, cv))
 
     # -- single-frame entry points ------------------------------------------
     def set_ref(self, ref):
