@@ -181,6 +181,11 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
     const int chunk = (total + nx - 1) / nx;
     const int u_end = min((xcd + 1) * chunk, total);
 
+    // the reference (with the slack rows the unclamped window loads reach into) and its
+    // sum(r) table as buffers
+    const __amdgpu_buffer_rsrc_t r_ref = buf_rsrc(ref, (uint32_t)((g.H + kMe16Rows + 2) * g.pitch));
+    const __amdgpu_buffer_rsrc_t r_sums = buf_rsrc(sums, (uint32_t)(g.N * kMe16SumStride * 4));
+
     // ---- per-lane offsets, once ---------------------------------------------------
     uint32_t o_blk[3], o_cq[4], o_new_src[Cfg::kNewN], o_new_dst[Cfg::kNewN];
     int o_new_row[Cfg::kNewN];
@@ -211,7 +216,9 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
       const int fc = active ? f : n_frames - 1;           // idle waves: in-bounds dummy loads
       const int by0 = seg * seg_len, by1 = min(by0 + seg_len, g.nby);
       const int x = bxi * BS, j_min = max(x - WIN, 0), j_max = min(x + WIN, g.W);
-      const uint8_t *__restrict__ colbase = ref + (size_t)(3 * j_min);  // uniform
+      const uint32_t col_off = (uint32_t)(3 * j_min);  // window's left edge, bytes into a row
+      // this unit's current frame as a buffer (uniform base; lane offsets stay 32-bit)
+      const __amdgpu_buffer_rsrc_t r_cur = buf_rsrc(curs + (size_t)fc * cur_stride, (uint32_t)(g.H * g.pitch + 64));  // + the slot's slack: the last row's unaligned dwords reach past it
       // candidate columns of this block column (motion.py:137-140) and cand / ncj by
       // multiplication (cand < 128, ncj <= 10): once per unit, not a division per block
       const int rj = j_max - BS - j_min;
@@ -223,12 +230,12 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
       // ---- the segment's first window: rows B .. B+63, cooperatively -----------------
       if (W > 1) wg_lds_barrier();  // everybody is done with the previous unit's window
       {
-          const uint8_t *__restrict__ wsrc = colbase + (size_t)B * g.pitch;
+          const uint32_t wsrc = (uint32_t)(B * g.pitch) + col_off;
           uint4 stg[Cfg::kFillN];
 #pragma unroll
           for (int q = 0; q < Cfg::kFillN; q++) {
               const int e = min(tid + Cfg::kLanes * q, 64 * NG - 1), row = e / NG, gg = e - row * NG;
-              stg[q] = load16_any_align(wsrc + (size_t)row * g.pitch + 15 * gg);
+              stg[q] = buf_ld128(r_ref, (uint32_t)(row * g.pitch + 15 * gg), wsrc);
           }
 #pragma unroll
           for (int q = 0; q < Cfg::kFillN; q++) {
@@ -245,27 +252,21 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
       }
 
       auto issue = [&](int byy, int Bwin, Me16gRegs<W> &R) {
-          const size_t blk_off = (size_t)(byy * BS) * g.pitch + (size_t)(48 * bxi);
-          const uint8_t *__restrict__ cblk = curs + (size_t)fc * cur_stride + blk_off;
-          const uint8_t *__restrict__ rblk = ref + blk_off;
+          const uint32_t blk_off = (uint32_t)((byy * BS) * g.pitch + 48 * bxi);
 #pragma unroll
           for (int t = 0; t < 3; t++) {
-              R.rv[t] = *(const uint32_t *)(rblk + o_blk[t]);
-              R.cv[t] = *(const uint32_t *)(cblk + o_blk[t]);
+              R.rv[t] = buf_ld32(r_ref, o_blk[t], blk_off);
+              R.cv[t] = buf_ld32(r_cur, o_blk[t], blk_off);
           }
 #pragma unroll
-          for (int t = 0; t < 4; t++) {
-              uint32_t v;
-              __builtin_memcpy(&v, cblk + o_cq[t], 4);
-              R.cq[t] = v;
-          }
-          const uint32_t *__restrict__ sb = sums + (size_t)(byy * g.nbx + bxi) * kMe16SumStride;
-          R.sr[0] = sb[lane];
-          R.sr[1] = sb[lane + 64];
+          for (int t = 0; t < 4; t++) R.cq[t] = buf_ld32(r_cur, o_cq[t], blk_off);  // unaligned dwords
+          const uint32_t sb = (uint32_t)((byy * g.nbx + bxi) * (kMe16SumStride * 4));
+          R.sr[0] = buf_ld32(r_sums, (uint32_t)(4 * lane), sb);
+          R.sr[1] = buf_ld32(r_sums, (uint32_t)(4 * lane + 256), sb);
           // this lane's share of rows Bwin + 64 .. Bwin + 79 (what the block below adds)
-          const uint8_t *__restrict__ nsrc = colbase + (size_t)(Bwin + 64) * g.pitch;
+          const uint32_t nsrc = (uint32_t)((Bwin + 64) * g.pitch) + col_off;
 #pragma unroll
-          for (int t = 0; t < Cfg::kNewN; t++) R.nw[t] = load16_any_align(nsrc + o_new_src[t]);
+          for (int t = 0; t < Cfg::kNewN; t++) R.nw[t] = buf_ld128(r_ref, o_new_src[t], nsrc);
       };
 
       Me16gRegs<W> A;
@@ -395,7 +396,7 @@ inline int me16g_group() {
     static const int v = [] {
         const char *e = getenv("VCS_ME16_GROUP");
         const int w = e ? atoi(e) : 4;
-        return (w == 0 || w == 1 || w == 2 || w == 4 || w == 8) ? w : 4;
+        return (w >= 0 && w <= 6) || w == 8 ? w : 4;
     }();
     return v;
 }
@@ -466,6 +467,9 @@ inline int launch_me_group(const Geom &g, hipStream_t stream, int cus, const uin
     if (w == 1) { if (p == 2) VCS_ME16G(1, 2); if (p == 4) VCS_ME16G(1, 4); VCS_ME16G(1, 3); }
     if (w == 2) { if (p == 2) VCS_ME16G(2, 2); if (p == 4) VCS_ME16G(2, 4); VCS_ME16G(2, 3); }
     if (w == 8) { if (p == 2) VCS_ME16G(8, 2); if (p == 4) VCS_ME16G(8, 4); VCS_ME16G(8, 3); }
+    if (w == 3) { if (p == 3) VCS_ME16G(3, 3); VCS_ME16G(3, 4); }
+    if (w == 5) { if (p == 3) VCS_ME16G(5, 3); VCS_ME16G(5, 4); }
+    if (w == 6) { if (p == 3) VCS_ME16G(6, 3); VCS_ME16G(6, 4); }
     if (p == 2) VCS_ME16G(4, 2);
     if (p == 3) VCS_ME16G(4, 3);
     VCS_ME16G(4, 4);

@@ -98,6 +98,9 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
     const int chunk = (total + nx - 1) / nx;
     const int u_end = min((xcd + 1) * chunk, total);
 
+    const __amdgpu_buffer_rsrc_t r_ref = buf_rsrc(ref, (uint32_t)((g.H + kMe16Rows + 2) * g.pitch));
+    const __amdgpu_buffer_rsrc_t r_sums = buf_rsrc(sums, (uint32_t)(g.N * kMe8SumStride * 4));
+
     // ---- per-lane offsets, once ---------------------------------------------------
     const int e0 = min(lane, 47), row0 = e0 / 6, col0 = e0 - row0 * 6;
     const uint32_t o_blk = (uint32_t)(row0 * g.pitch + 4 * col0);
@@ -125,7 +128,8 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
       const int fc = active ? f : n_frames - 1;
       const int by0 = seg * seg_len, by1 = min(by0 + seg_len, g.nby);
       const int x = bxi * BS, j_min = max(x - WIN, 0), j_max = min(x + WIN, g.W);
-      const uint8_t *__restrict__ colbase = ref + (size_t)(3 * j_min);
+      const uint32_t col_off = (uint32_t)(3 * j_min);
+      const __amdgpu_buffer_rsrc_t r_cur = buf_rsrc(curs + (size_t)fc * cur_stride, (uint32_t)(g.H * g.pitch + 64));  // + the slot's slack: the last row's unaligned dwords reach past it
       // candidate columns of this block column (motion.py:137-140); lane / ncj by multiplication
       const int rj = j_max - BS - j_min;
       const int ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
@@ -136,12 +140,12 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
       int Bslot = B % RING;
       if (W > 1) wg_lds_barrier();
       {
-          const uint8_t *__restrict__ wsrc = colbase + (size_t)B * g.pitch;
+          const uint32_t wsrc = (uint32_t)(B * g.pitch) + col_off;
           uint4 stg[Cfg::kFillN];
 #pragma unroll
           for (int q = 0; q < Cfg::kFillN; q++) {
               const int e = min(tid + Cfg::kLanes * q, kMe8Rows * NG - 1), row = e / NG, gg = e - row * NG;
-              stg[q] = load16_any_align(wsrc + (size_t)row * g.pitch + 9 * gg);
+              stg[q] = buf_ld128(r_ref, (uint32_t)(row * g.pitch + 9 * gg), wsrc);
           }
 #pragma unroll
           for (int q = 0; q < Cfg::kFillN; q++) {
@@ -159,18 +163,14 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
       }
 
       auto issue = [&](int byy, int Bwin, Me8gRegs<W> &R) {
-          const size_t blk_off = (size_t)(byy * BS) * g.pitch + (size_t)(24 * bxi);
-          const uint8_t *__restrict__ cblk = curs + (size_t)fc * cur_stride + blk_off;
-          const uint8_t *__restrict__ rblk = ref + blk_off;
-          R.rv = *(const uint32_t *)(rblk + o_blk);
-          R.cv = *(const uint32_t *)(cblk + o_blk);
-          uint32_t v;
-          __builtin_memcpy(&v, cblk + o_cq, 4);
-          R.cq = v;
-          R.sr = sums[(size_t)(byy * g.nbx + bxi) * kMe8SumStride + lane];
-          const uint8_t *__restrict__ nsrc = colbase + (size_t)(Bwin + kMe8Rows) * g.pitch;
+          const uint32_t blk_off = (uint32_t)((byy * BS) * g.pitch + 24 * bxi);
+          R.rv = buf_ld32(r_ref, o_blk, blk_off);
+          R.cv = buf_ld32(r_cur, o_blk, blk_off);
+          R.cq = buf_ld32(r_cur, o_cq, blk_off);  // unaligned dword
+          R.sr = buf_ld32(r_sums, (uint32_t)(4 * lane), (uint32_t)((byy * g.nbx + bxi) * (kMe8SumStride * 4)));
+          const uint32_t nsrc = (uint32_t)((Bwin + kMe8Rows) * g.pitch) + col_off;
 #pragma unroll
-          for (int t = 0; t < Cfg::kNewN; t++) R.nw[t] = load16_any_align(nsrc + o_new_src[t]);
+          for (int t = 0; t < Cfg::kNewN; t++) R.nw[t] = buf_ld128(r_ref, o_new_src[t], nsrc);
       };
 
       Me8gRegs<W> A;

@@ -62,6 +62,24 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- buffer loads: SGPR resource + 32-bit lane offset + uniform offset ----------------
+// The flat-address form of a load keeps every per-lane byte offset as a 64-bit register
+// pair and spends a 64-bit vector add per load to form the address.  A raw buffer load
+// takes the (wave-uniform) base as a 4-SGPR resource, a 32-bit per-lane offset and a
+// uniform offset in an SGPR; reads past `bytes` return 0 instead of faulting.  Unaligned
+// dword / 16-byte accesses are fine on gfx950 (tools/buf_test.hip).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t buf_ld32(__amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t uni_off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)uni_off, 0);
+}
+__device__ __forceinline__ uint4 buf_ld128(__amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t uni_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)uni_off, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // ---- packed-byte arithmetic ---------------------------------------------
 // Per-byte (a - b) mod 256 on four packed bytes, no borrow across bytes.
 __device__ __forceinline__ uint32_t sub_u8x4(uint32_t a, uint32_t b) {
