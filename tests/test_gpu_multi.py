@@ -54,7 +54,7 @@ def test_encode_gop_one_call(vh, oracle, n_ctx, n_p):
 
 
 @pytest.mark.parametrize("n_ctx", [1, 3])
-def test_group_pipelined_gops(vh, oracle, n_ctx):
+def test_group_pipelined_gops(vh, oracle, n_ctx, monkeypatch):
     """The pieces, pipelined as bench.py drives them: encode GOP k, prefetch the I frame of GOP
     k+1 beside it, rotate through resident slot sets; uneven shards (7 frames over 3)."""
     from synth import synth_gop
@@ -64,7 +64,8 @@ def test_group_pipelined_gops(vh, oracle, n_ctx):
     g = vh.Group(ctxs)
     try:
         assert g.world == n_ctx and g.rank0 == 0 and g.n_local == n_ctx
-        assert g.transport == (1 if n_ctx == 1 else 3)   # RCCL with one device; copies when shared
+        # RCCL with one device (in sequence: nothing to overlap with); copies, overlapped, when shared
+        assert g.transport == (2 if n_ctx == 1 else 3)
         g.layout(n_p, with_decode=True, sets=sets)
         table = [g.shard(i) for i in range(n_ctx)]
         assert table == [vh.shard_frames(n_p, n_ctx, r) for r in range(n_ctx)]
@@ -242,3 +243,33 @@ def test_pipelined_encoder_dropin(vh, oracle, capsys):
             assert np.array_equal(np.asarray(fr.mv), omv), n
             assert np.array_equal(np.stack(list(fr.r)), oplanes), n
     capsys.readouterr()
+
+
+@pytest.mark.parametrize("serial", ["0", "1"])
+def test_group_schedules_forced(vh, oracle, serial, monkeypatch):
+    """Both schedules on both transports: VCS_GROUP_SERIAL=0 puts the one-device RCCL group's
+    collectives on their own stream (what N > 1 does by default), =1 puts the copy transport in
+    sequence on the kernels' stream."""
+    from synth import synth_gop
+    monkeypatch.setenv("VCS_GROUP_SERIAL", serial)
+    H, W, bs, n_p = 144, 176, 16, 5
+    for n_ctx in (1, 2):
+        ctxs = [vh.Context(H, W, bs) for _ in range(n_ctx)]
+        try:
+            g = vh.Group(ctxs)
+            assert g.transport == {("0", 1): 1, ("1", 1): 2, ("0", 2): 3, ("1", 2): 4}[(serial, n_ctx)]
+            g.layout(n_p)
+            for seed in (31, 32, 33):
+                ref, frames = synth_gop(H, W, n_p, seed=seed)
+                g.set_ref(ref)
+                g.upload(0, frames)
+                g.encode()
+                g.prefetch_ref()
+                mv, ns = g.get_mv()
+                for k in range(n_p):
+                    omv, ons = oracle.me(frames[k], ref, bs)
+                    assert np.array_equal(mv[k], omv) and ns[k] == ons, (n_ctx, seed, k)
+            g.close()
+        finally:
+            for c in ctxs:
+                c.close()

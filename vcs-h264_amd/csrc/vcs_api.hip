@@ -85,6 +85,8 @@ struct vcs_ctx {
     void *g_planes = nullptr;
     hipEvent_t xev = nullptr;  // cross-stream ordering with a foreign (torch / RCCL) stream
     vcs_group *group = nullptr;  // multi-GPU group this context is a shard of (vcs_multi.hpp)
+    hipEvent_t ev_me_done = nullptr;  // group members: the last GOP's search kernel has finished
+    bool me_done_rec = false;
     // pipelined single-frame feeder (vcs_async_reserve)
     hipStream_t s_in = nullptr, s_out = nullptr;
     std::vector<AsyncSlot> aslots;
@@ -705,6 +707,7 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     free_async(c);
     if (c->s_me) { hipStreamSynchronize(c->s_me); hipStreamDestroy(c->s_me); }
     if (c->s_tail) { hipStreamSynchronize(c->s_tail); hipStreamDestroy(c->s_tail); }
+    if (c->ev_me_done) hipEventDestroy(c->ev_me_done);
     if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->ev_me) hipEventDestroy(c->ev_me);
     if (c->ev_tail) hipEventDestroy(c->ev_tail);
@@ -1100,6 +1103,10 @@ int vcs_gop_encode(vcs_ctx *c, int first, int n) {
     }
     rc = launch_me(c, c->d_ref, curs, c->Fs, n, mv, c->g_ns + first, nullptr);
     if (rc) return rc;
+    if (c->ev_me_done) {  // the group's collectives start behind the search, beside the tail
+        HIP_TRY(c, hipEventRecord(c->ev_me_done, c->stream));
+        c->me_done_rec = true;
+    }
     if (N == 0)  // no full motion block: the prediction is all zero (motion.py:45-46)
         return launch_fdct<0>(c, VCS_T_ENC_TAIL, curs, c->Fs, nullptr, nullptr, n, planes, pe);
     return launch_fdct<1>(c, VCS_T_ENC_TAIL, curs, c->Fs, c->d_ref, mv, n, planes, pe);

@@ -91,13 +91,20 @@ void shard_of(int n, int world, int rank, int *first, int *count) {
     *first = rank * base + (rank < extra ? rank : extra);
 }
 
-bool group_serial_env() {
+// VCS_GROUP_SERIAL=1: collectives on the kernels' stream, strictly in sequence; =0: overlapped
+// on their own stream.  Default: overlapped when there is somebody to exchange with; a
+// one-shard group's "collectives" are local copies with nothing to hide behind the kernels,
+// and the cross-stream waits cost more than they save (measured: +4 % overlapped, +1.5-2 %
+// in sequence, against the plain single-context path).
+bool group_overlap(int world) {
     const char *e = getenv("VCS_GROUP_SERIAL");
-    return e && e[0] == '1';
+    if (e && e[0] == '1') return false;
+    if (e && e[0] == '0') return true;
+    return world > 1;
 }
 
 int group_init_common(vcs_group *g) {
-    g->overlap = !group_serial_env();
+    g->overlap = group_overlap(g->world);
     for (auto &p : g->per) {
         vcs_ctx *c = p.c;
         G_HIP(g, hipSetDevice(c->device));
@@ -106,8 +113,14 @@ int group_init_common(vcs_group *g) {
         p.refbuf[0] = c->d_ref;
         p.refbuf[1] = c->d_ref_alt;
         if (g->overlap) {
-            G_HIP(g, hipStreamCreateWithFlags(&p.cs, hipStreamNonBlocking));
+            // highest priority: the collectives' few workgroups must not queue behind the tail
+            // kernel's 117 k (VCS_GROUP_PRIO=0: default priority)
+            int lo = 0, hi = 0;
+            G_HIP(g, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const char *pe = getenv("VCS_GROUP_PRIO");
+            G_HIP(g, hipStreamCreateWithPriority(&p.cs, hipStreamNonBlocking, (pe && pe[0] == '0') ? 0 : hi));
             p.own_cs = true;
+            if (!c->ev_me_done) G_HIP(g, hipEventCreateWithFlags(&c->ev_me_done, hipEventDisableTiming));
         } else {
             p.cs = c->stream;
         }
@@ -170,6 +183,10 @@ int group_bcast(vcs_group *g, int b) {
         for (auto &p : g->per) {
             G_HIP(g, hipSetDevice(p.c->device));
             if (p.kern_rec[b] && p.cs != p.c->stream) G_HIP(g, hipStreamWaitEvent(p.cs, p.ev_kern[b], 0));
+            // ... and start behind the search kernel of the GOP being encoded: the copy kernels of
+            // the collective then run beside the HBM-bound tail instead of taking CUs from the
+            // search, whose persistent workgroups are dealt to a full chip
+            if (p.c->me_done_rec && p.cs != p.c->stream) G_HIP(g, hipStreamWaitEvent(p.cs, p.c->ev_me_done, 0));
         }
         G_NCCL(g, ncclGroupStart());
         for (size_t i = 0; i < g->per.size(); i++) {
@@ -189,6 +206,7 @@ int group_bcast(vcs_group *g, int b) {
         for (auto &p : g->per) {
             G_HIP(g, hipSetDevice(p.c->device));
             if (p.kern_rec[b] && p.cs != p.c->stream) G_HIP(g, hipStreamWaitEvent(p.cs, p.ev_kern[b], 0));
+            if (p.c->me_done_rec && p.cs != p.c->stream) G_HIP(g, hipStreamWaitEvent(p.cs, p.c->ev_me_done, 0));
             G_HIP(g, hipStreamWaitEvent(p.cs, g->ev_iframe, 0));
             G_HIP(g, hipMemcpyAsync(p.refbuf[b], g->d_iframe, F, hipMemcpyDeviceToDevice, p.cs));
         }
@@ -240,6 +258,7 @@ int vcs_group_destroy(vcs_group *g) {
         if (p.own_cs && p.cs) hipStreamDestroy(p.cs);
         // the contexts go back to a plain single-GPU state: refbuf[0/1] are their two buffers
         p.c->group = nullptr;
+        if (p.c->ev_me_done) { hipEventDestroy(p.c->ev_me_done); p.c->ev_me_done = nullptr; p.c->me_done_rec = false; }
     }
     if (!g->per.empty()) hipSetDevice(g->per[0].c->device);
     hipFree(g->d_iframe);
