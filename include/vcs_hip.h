@@ -215,7 +215,11 @@ int vcs_encode_gop(vcs_ctx *const *ctxs, int n_ctx, const uint8_t *frames, int n
  *   vcs_group_upload       P frames [first_p, first_p+n) of the GOP from host
  *                          memory; each local shard takes its part of the range.
  *   vcs_group_set_ref      stages the next GOP's I frame on shard 0's GPU (no-op in
- *                          processes that do not hold shard 0).
+ *                          processes that do not hold shard 0).  It supersedes a
+ *                          prefetch that was enqueued before it.  With one process
+ *                          per GPU EVERY rank makes the same sequence of set_ref /
+ *                          prefetch_ref / encode calls (ref_bgr may be NULL off
+ *                          shard 0): the calls carry collectives.
  *   vcs_group_prefetch_ref enqueues the broadcast of the staged I frame into the
  *                          contexts' ALTERNATE reference buffers, on the
  *                          collectives' stream -- beside the kernels of the GOP

@@ -433,7 +433,12 @@ int vcs_group_upload(vcs_group *g, int first_p, int n, const uint8_t *frames) {
 
 int vcs_group_set_ref(vcs_group *g, const uint8_t *ref_bgr) {
     if (!g) return gfail(nullptr, VCS_E_ARG, "null group");
-    if (g->rank0 != 0) return VCS_OK;  // only the process that holds shard 0 feeds the I frame
+    if (g->rank0 != 0) {
+        // only the process that holds shard 0 feeds the I frame; the others just keep their
+        // sequence of collectives in step with it (see the end of this function)
+        if (g->gop_prefetched > g->gop) g->gop_prefetched = g->gop;
+        return VCS_OK;
+    }
     if (!ref_bgr) return gfail(g, VCS_E_ARG, "null reference frame");
     auto &p0 = g->per[0];
     G_HIP(g, hipSetDevice(p0.c->device));
@@ -445,6 +450,10 @@ int vcs_group_set_ref(vcs_group *g, const uint8_t *ref_bgr) {
     G_HIP(g, hipEventRecord(g->ev_iframe, p0.cs));
     G_HIP(g, hipStreamSynchronize(p0.cs));  // the host buffer is the caller's again
     g->iframe_valid = true;
+    // a broadcast already enqueued for the next GOP carried the PREVIOUS I frame: this one
+    // supersedes it (the next vcs_group_encode / _prefetch_ref broadcasts again, behind it on
+    // the same stream, into the same buffer)
+    if (g->gop_prefetched > g->gop) g->gop_prefetched = g->gop;
     return VCS_OK;
 }
 

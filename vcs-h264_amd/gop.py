@@ -137,8 +137,7 @@ class DistGopEncoder:
 
     # -- product path -------------------------------------------------------
     def _encode_gpu(self, ref, frames):
-        if self.rank == 0:
-            self.g.set_ref(ref)
+        self.g.set_ref(ref if self.rank == 0 else None)   # every rank: keeps the collectives in step
         if self.count:
             self.g.upload(self.first, frames)
         self.g.encode()

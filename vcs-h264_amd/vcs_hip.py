@@ -685,7 +685,10 @@ class Group:
                                             frames.ctypes.data_as(_u8p)))
 
     def set_ref(self, ref):
+        """Stage the next GOP's I frame.  EVERY process of a process-per-GPU job calls this (it
+        keeps their sequences of collectives in step); only the one holding shard 0 needs `ref`."""
         if self.rank0 != 0:
+            self._ck(self._lib.vcs_group_set_ref(self._g, None))
             return
         ref = _frame(ref, self.contexts[0].shape, "reference frame")
         self._ck(self._lib.vcs_group_set_ref(self._g, ref.ctypes.data_as(_u8p)))
