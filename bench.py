@@ -220,8 +220,9 @@ def main():
     N, F = ctx.N, ctx.F
     n_total = 29 if args.strong else args.frames * n_gpus   # P frames of the (long) GOP
     group = None
+    launched = "RANK" in os.environ          # under torch.distributed.run (or any launcher)
     if use_group:
-        if world > 1:
+        if world > 1 or launched:            # one process per GPU: ncclCommInitRank
             uid = vcs_hip.rendezvous_unique_id(rank, world)
             group = vcs_hip.Group.from_rank(ctx, uid, world, rank)
             group.barrier()
@@ -372,7 +373,7 @@ def main():
                        "searched_block_fraction": round(searched, 4),
                        "resident_gop_sets_encoded_in_turn": sets,
                        "parallelism": ("P frames sharded over %d GPU(s), %s"
-                                       % (n_gpus, "one process per GPU" if world > 1 else
+                                       % (n_gpus, "one process per GPU" if (world > 1 or (launched and use_group)) else
                                           "one process, one context per GPU" if n_gpus > 1 else "single context")),
                        "collectives": ("none" if group is None else
                                        "in-library RCCL broadcast (I frame) + all-gather (vectors) per GOP: " + transport)},

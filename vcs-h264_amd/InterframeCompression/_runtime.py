@@ -72,17 +72,24 @@ def invalidate_ref(ctx):
 
 
 def ensure_q(ctx, Q, coeff_mode=0):
+    # per-frame call: the token is the tables' bytes (1.5 KB), taken without building a stacked
+    # copy when they are float64 arrays already, as the drop-in modules' own tables are
+    try:
+        tok = (b"".join(p.tobytes() if p.dtype == np.float64 else np.asarray(p, np.float64).tobytes()
+                        for p in Q), coeff_mode)
+    except AttributeError:
+        tok = (b"".join(np.asarray(p, np.float64).tobytes() for p in Q), coeff_mode)
+    if ctx._q_token == tok:
+        return
     q = np.ascontiguousarray(np.stack([np.asarray(p, np.float64) for p in Q]))
     if q.shape != (3, 8, 8):
         # same failure class as np.true_divide(d, self.Q[channel]) in the reference
         raise ValueError("operands could not be broadcast together: Q tables must be 8x8, got %s"
                          % (q.shape,))
-    tok = (q.tobytes(), coeff_mode)
-    if ctx._q_token != tok:
-        # Q and coeff_mode only: the motion-search parameters (window, stride,
-        # motion.SIMILARITY_THRESHOLD) keep whatever MotionProcessor pushed
-        ctx.set_params(Q=q, coeff_mode=coeff_mode)
-        ctx._q_token = tok
+    # Q and coeff_mode only: the motion-search parameters (window, stride,
+    # motion.SIMILARITY_THRESHOLD) keep whatever MotionProcessor pushed
+    ctx.set_params(Q=q, coeff_mode=coeff_mode)
+    ctx._q_token = tok
 
 
 # ---- pipelined frame feeder (vcs_encode_p_async / vcs_wait) -------------

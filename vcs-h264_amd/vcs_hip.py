@@ -763,7 +763,7 @@ def rendezvous_unique_id(rank, world, timeout_s=180.0, tag=None, make_id=None):
     import time
     make_id = make_id or comm_unique_id
     if world == 1:
-        return make_id()
+        return make_id()      # nobody to hand it to
     tag = tag or _job_tag()
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
     path = os.path.join(base, "vcs_hip_rccl_id_%d_%s_w%d" % (os.getuid(), tag, world))
