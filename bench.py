@@ -163,6 +163,52 @@ def host_path(H, W, bs, ref, frames, device, n_frames=48):
     return out
 
 
+def intra_mode(args, real_stdout):
+    """BASELINE config 5: intramodes.py 4x4 intra prediction + the 4x4 core
+    transform on a 1080p I frame (resized to multiples of 16 as intraframe.py:324 does: 1920 x
+    1072), one GPU.  Kernel-only times (HIP events), blocks/ms and achieved HBM GB/s per kernel;
+    the entry points themselves also move the float64 planes over PCIe (host_ms)."""
+    import vcs_hip
+    H, W = 1072, 1920
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = (128 + 70 * np.sin(xx / 23.0) * np.cos(yy / 17.0)).astype(np.int16)
+    Y, Cr, Cb = [np.clip(base + rng.integers(-30, 31, (H, W)), 0, 255).astype(np.uint8) for _ in range(3)]
+    hw = H * W
+    res = {}
+    with vcs_hip.Context(H, W, 16) as c:
+        yres = c.intra_luma(Y, 4)[0]
+        jobs = (("luma4x4", lambda: c.intra_luma(Y, 4), hw // 16, hw + 16 * hw + 8 * (hw // 16)),
+                ("luma16x16", lambda: c.intra_luma(Y, 16), hw // 256, hw + 16 * hw + 8 * (hw // 256)),
+                ("chroma8x8", lambda: c.intra_chroma(Cr, Cb), hw // 64, 2 * hw + 32 * hw + 8 * (hw // 64)),
+                ("transform4x4", lambda: c.intra_transform4x4(yres), hw // 16, 16 * hw))
+        for name, fn, blocks, alg in jobs:
+            fn()
+            c.timing_enable(True)
+            c.timing_reset()
+            t0 = time.perf_counter()
+            for _ in range(max(1, args.steps // 4)):
+                fn()
+            host = (time.perf_counter() - t0) / max(1, args.steps // 4)
+            ms, l = c.timing()
+            c.timing_enable(False)
+            k_ms = ms[vcs_hip.T_AUX] / max(1, int(l[vcs_hip.T_AUX]))
+            res[name] = {"kernel_ms": round(k_ms, 4), "blocks": blocks,
+                         "blocks_per_ms": round(blocks / k_ms, 1),
+                         "algorithmic_bytes": alg, "achieved_gbs": round(alg / (k_ms * 1e-3) / 1e9, 1),
+                         "hbm_frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "host_ms_incl_pcie": round(host * 1e3, 3)}
+    out = {"metric": "intra prediction (config 5), 4x4 luma blocks/ms at 1080p", "value": res["luma4x4"]["blocks_per_ms"],
+           "unit": "4x4 blocks/ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": res["luma4x4"]["kernel_ms"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u8 -> f64 (the reference's output type)", "data": "synthetic",
+           "config": {"workload": "configs[4]: luma4x4 / luma16x16 / chroma8x8 / transform4x4 on a %dx%d I frame" % (W, H)},
+           "kernels": res,
+           "note": "chroma8x8 is serial down each block column (the reference predicts Cb from the residual "
+                   "above, intraframe.py:266): %d waves for the frame" % (W // 8)}
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +230,8 @@ def main():
                     help="skip the secondary measurements (one-GOP loop, host path, parity, bandwidth)")
     ap.add_argument("--with-decode", action="store_true",
                     help="also time the decode kernel over the GOP (reported next to the line)")
+    ap.add_argument("--intra", action="store_true",
+                    help="BASELINE config 5 instead: the intra-prediction kernels on a 1080p I frame")
     ap.add_argument("--same-ref", action="store_true",
                     help="diagnostic: do not declare a new I frame per step")
     args = ap.parse_args()
@@ -208,6 +256,10 @@ def main():
     import vcs_hip
     from synth import synth_gop
 
+    if args.intra:
+        if rank == 0:
+            intra_mode(args, real_stdout)
+        return
     H = args.height or (2160 if args.strong else 1080)
     W = args.width or (3840 if args.strong else 1920)
     bs = args.bs

@@ -62,12 +62,18 @@ __device__ __forceinline__ void me16g_step(Me16Q &a, Me16Q &c, const void *na, c
     for (int d = 0; d < 13; d++) t[d] = __builtin_amdgcn_lerp(r[d], nc[d], 0x01010101u);
     __builtin_amdgcn_sched_barrier(0);
     if (NEXT) {
+#ifndef VCS_EXP_NOCUR   // experiment builds only (never shipped): sensitivity to the broadcast reads
         me16_ld(c, nc_);
+#endif
+#ifndef VCS_EXP_NOWIN
         me16_ld(a, na);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifndef VCS_EXP_NOAND
 #pragma unroll
     for (int d = 0; d < 13; d++) t[d] &= 0x80808080u;
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // popcount + accumulate selects to ONE v_bcnt_u32_b32 (x, acc); the empty asm keeps hipcc
     // from re-associating the chain into v_bcnt(x, 0) + v_add3 (as inline asm text the
