@@ -115,16 +115,17 @@ def host_path(H, W, bs, ref, frames, device, n_frames=48):
     import encoder as E
     import vcs_hip
     from _runtime import release_contexts
-    ring = [vcs_hip.pinned_empty((H, W, 3)) for _ in range(6)]   # the frame feeder's buffers
     pattern = ["I"] + ["P"] * 29
     res = {}
     for label, kw in (("pipelined", {}), ("synchronous", {"async_slots": 0})):
         enc = E.Encoder(pattern=pattern, shape=[H, W], block_size=bs, with_DCT=True, dct_block_size=8,
                         device=device, resident=True, **kw)
         sink = io.StringIO()
+        iframe = vcs_hip.pinned_empty((H, W, 3))
+        iframe[...] = ref
+        ring = [iframe] + [enc.next_buffer() for _ in range(5)]   # the feeder's page-locked ring
         for k in range(1, 6):
             ring[k][...] = frames[k % len(frames)]
-        ring[0][...] = ref
 
         def run(first, n, produce):
             t0 = time.perf_counter()

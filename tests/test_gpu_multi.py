@@ -234,6 +234,10 @@ def test_pipelined_encoder_dropin(vh, oracle, capsys):
     enc = E.Encoder(pattern=["I"] + ["P"] * 4, shape=[H, W], block_size=16, with_DCT=True,
                     dct_block_size=8, resident=True, async_slots=2)
     for n, f in enumerate(seq):
+        if n % 2:                       # every other frame through the feeder's page-locked ring
+            buf = enc.next_buffer()
+            buf[...] = f
+            f = buf
         enc.encode_frame(f, n)
     enc.flush()
     for n, fr in enumerate(enc.encoded_frames):

@@ -405,8 +405,12 @@ def test_gop_1080p_vs_oracle(vh, oracle):
             assert np.array_equal(planes, oplanes), k
             dec = c.gop_get_decoded(k)
             assert np.array_equal(dec, oracle.decode_p(mv[k], oplanes, ref, 16))
-            # round trip: the un-rounded quantiser makes the codec lossless up to
-            # the +-1 truncation noise in YCrCb and the colour conversion itself
+            # Round-trip PROPERTY (the parity assertions are the exact ones above).  The
+            # quantiser never rounds, so the only losses are the truncating float64 -> uint8
+            # store of DCTcompressor.py:88 (up to -1 in each of Y, Cr, Cb) and the two integer
+            # colour conversions; through the inverse matrix (B = Y + 1.77 (Cb - 128), ...) that
+            # is a few levels per channel.  Measured on this content: max 6, mean 1.03 -- the
+            # bounds leave room for other content, they are not a tolerance on parity.
             err = np.abs(dec.astype(np.int16) - frames[k].astype(np.int16))
             err = np.minimum(err, 256 - err)
             assert err.max() <= 6 and err.mean() < 1.5
@@ -669,8 +673,8 @@ def test_gop_1080p_rolling_kernel(vh, oracle):
 
 
 def test_forced_kernel_variants_subprocess():
-    """The same parity cases with the rolling-window kernel forced on small and
-    ragged frames (VCS_ME16_ROLL=2), with it disabled (=0), and with the generic
+    """The same parity cases with every specialised search kernel forced on small and
+    ragged frames (VCS_ME16_ROLL=2 and friends), with them disabled (=0), with the generic
     kernel forced (VCS_ME_GENERIC=1), and the DCT cases with the IEEE division
     sequence instead of the exact 3-FMA one (VCS_FAST_DIV=0): one child process per setting."""
     import os
@@ -680,7 +684,12 @@ def test_forced_kernel_variants_subprocess():
     sel = ("golden_me_small or golden_me_edges or me_vs_oracle_shapes or static_heavy or "
            "4k_frame or empty_and_tiny or golden_real_small or gop_1080p_vs_oracle")
     dct = "golden_dct_small or encode_decode_vs_oracle or dct_extremes or coeff_modes"
-    for env_add, k in (({"VCS_ME16_ROLL": "2"}, sel), ({"VCS_ME16_ROLL": "0"}, sel),
+    # ROLL=2: the shared-window kernels (k_me16g, k_me8g) on every frame size; ROLL=2 with
+    # GROUP=0: the private-window rolling kernel (k_me16r); ROLL=0: k_me16 / k_me8
+    for env_add, k in (({"VCS_ME16_ROLL": "2"}, sel),
+                       ({"VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "0", "VCS_ME8_GROUP": "0"}, sel),
+                       ({"VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "2", "VCS_ME16_WPS": "3"}, sel),
+                       ({"VCS_ME16_ROLL": "0"}, sel),
                        ({"VCS_ME_GENERIC": "1"}, sel), ({"VCS_FAST_DIV": "0"}, dct)):
         env = dict(os.environ, **env_add)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),

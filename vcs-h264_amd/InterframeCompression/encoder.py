@@ -51,6 +51,20 @@ class Encoder:
             async_slots = int(os.environ.get("VCS_ASYNC_SLOTS", "3"))
         self.async_slots = int(async_slots) if self.resident else 0
 
+    def next_buffer(self):
+        """The frame feeder's producer side: a page-locked H x W x 3 uint8 array that is safe to
+        overwrite NOW (a ring of async_slots + 2 buffers, so the frames still in flight keep
+        theirs).  Write the next captured frame into it -- e.g. `cap.read(image=buf)` in an adapted
+        main.py -- and hand it to encode_frame: the upload is then a DMA straight out of it."""
+        from _runtime import vcs_hip
+        if getattr(self, "_ring", None) is None:
+            shape = (self.MotionProcessor.shape[0], self.MotionProcessor.shape[1], 3)
+            self._ring = [vcs_hip.pinned_empty(shape) for _ in range(max(self.async_slots, 1) + 2)]
+            self._ring_pos = 0
+        buf = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        return buf
+
     def flush(self):
         """Wait for every frame still in flight (pipelined resident mode)."""
         flush_async(self.MotionProcessor._ctx())
