@@ -106,7 +106,7 @@ class Pending:
     def complete(self):
         if self.mv is None:
             mv, ns = self.ctx.wait(self.slot)
-            self.mv, self.n_static = mv.astype(np.int64), ns
+            self.mv, self.n_static = mv, ns   # int16 (N, 2), as the kernel wrote it
             if self.ctx._pending[self.slot] is self:
                 self.ctx._pending[self.slot] = None
             self.cur = None

@@ -76,14 +76,17 @@ class LazyRowList(RowList):
     """A RowList whose array is still on its way back from the GPU (the pipelined frame
     feeder, Encoder(resident=True)): the first access of any kind waits for it."""
 
-    __slots__ = ("_pending",)
+    __slots__ = ("_pending", "_wide")
 
     def __init__(self, pending):
         self._pending = pending
+        self._wide = None
 
     @property
     def _a(self):
-        return self._pending.complete()
+        if self._wide is None:      # int64 like the default Encoder's vectors, converted once
+            self._wide = self._pending.complete().astype(np.int64)
+        return self._wide
 
     def __repr__(self):
         return "LazyRowList(%s)" % ("pending" if self._pending.mv is None else "%d x 2" % len(self))
