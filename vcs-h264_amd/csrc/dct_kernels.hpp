@@ -150,7 +150,11 @@ inline unsigned tail_grid(const Geom &g, int n_frames, int map) {
 // displacing the reference frame and the pixel rows in L2 (k_fdct 0.49 -> 0.42 ms at
 // 29 x 1080p).  Non-temporal *loads* of the pixel rows were measured too and lose
 // (0.52 ms): neighbouring lanes' unaligned dword loads share cache lines.
+#ifdef VCS_EXP_PLAIN_STORES   // experiment builds only
+#define VCS_NT_STORE(v, p) (*(p) = (v))
+#else
 #define VCS_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
 template <class T> struct Vec2 { typedef T type __attribute__((ext_vector_type(2))); };
 
 // --------------------------------------------------------------------------

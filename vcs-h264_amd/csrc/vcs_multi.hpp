@@ -48,6 +48,7 @@ struct vcs_group {
     size_t chunk = 0;       // bytes one shard contributes to the gather
     uint64_t gop = 0;       // GOPs encoded so far
     uint64_t gop_prefetched = 0;  // GOPs whose I frame has been broadcast (or enqueued)
+    int gather_pending = -1;      // stage buffer whose all-gather is still to be enqueued (-1: none)
     uint8_t *d_iframe = nullptr;  // on shard 0's device: the staged I frame of the next GOP
     hipEvent_t ev_iframe = nullptr;
     bool iframe_valid = false;
@@ -218,6 +219,44 @@ int group_bcast(vcs_group *g, int b) {
     return VCS_OK;
 }
 
+// Enqueues the pending all-gather (see vcs_group_encode).
+int group_flush_gather(vcs_group *g) {
+    if (g->gather_pending < 0) return VCS_OK;
+    const int b = g->gather_pending;
+    g->gather_pending = -1;
+    if (g->rccl) {
+        for (auto &p : g->per) {
+            G_HIP(g, hipSetDevice(p.c->device));
+            if (p.cs != p.c->stream) G_HIP(g, hipStreamWaitEvent(p.cs, p.ev_kern[b], 0));
+        }
+        G_NCCL(g, ncclGroupStart());
+        for (auto &p : g->per) {
+            hipSetDevice(p.c->device);
+            ncclResult_t r = ncclAllGather(p.stage[b], p.all[b], g->chunk, ncclUint8, p.comm, p.cs);
+            if (r != ncclSuccess) {
+                ncclGroupEnd();
+                return gfail(g, VCS_E_COMM, "ncclAllGather failed: %s", ncclGetErrorString(r));
+            }
+        }
+        G_NCCL(g, ncclGroupEnd());
+    } else {
+        for (size_t i = 0; i < g->per.size(); i++) {
+            auto &p = g->per[i];
+            G_HIP(g, hipSetDevice(p.c->device));
+            if (p.cs != p.c->stream) G_HIP(g, hipStreamWaitEvent(p.cs, p.ev_kern[b], 0));
+            for (auto &q : g->per)
+                G_HIP(g, hipMemcpyAsync(q.all[b] + (size_t)(g->rank0 + i) * g->chunk, p.stage[b], g->chunk,
+                                        hipMemcpyDeviceToDevice, p.cs));
+        }
+    }
+    for (auto &p : g->per) {
+        G_HIP(g, hipSetDevice(p.c->device));
+        G_HIP(g, hipEventRecord(p.ev_gather[b], p.cs));
+        p.gather_rec[b] = true;
+    }
+    return VCS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -245,6 +284,7 @@ int vcs_comm_unique_id(void *id, size_t bytes) {
 
 int vcs_group_destroy(vcs_group *g) {
     if (!g) return VCS_OK;
+    group_flush_gather(g);   // (keeps the ranks' collective sequences equal up to the end)
     group_sync_all(g);
     group_free_buffers(g);
     for (auto &p : g->per) {
@@ -385,6 +425,7 @@ int vcs_group_use_set(vcs_group *g, int set) {
 int vcs_group_layout_sets(vcs_group *g, int n_p_frames, int with_decode, int n_sets) {
     if (!g) return gfail(nullptr, VCS_E_ARG, "null group");
     if (n_sets < 1 || n_sets > 64) return gfail(g, VCS_E_ARG, "bad set count %d", n_sets);
+    { int rc0 = group_flush_gather(g); if (rc0) return rc0; }
     if (n_p_frames < 0 || n_p_frames > 4096 * g->world) return gfail(g, VCS_E_ARG, "bad frame count %d", n_p_frames);
     int rc = group_sync_all(g);
     if (rc) return rc;
@@ -460,17 +501,18 @@ int vcs_group_set_ref(vcs_group *g, const uint8_t *ref_bgr) {
 int vcs_group_prefetch_ref(vcs_group *g) {
     if (!g) return gfail(nullptr, VCS_E_ARG, "null group");
     if (g->rank0 == 0 && !g->iframe_valid) return gfail(g, VCS_E_STATE, "no I frame staged (vcs_group_set_ref)");
-    if (g->gop_prefetched > g->gop) return VCS_OK;  // already on its way
+    if (g->gop_prefetched > g->gop) return group_flush_gather(g);  // already on its way
     int rc = group_bcast(g, (int)(g->gop_prefetched & 1));
     if (rc) return rc;
     g->gop_prefetched++;
-    return VCS_OK;
+    return group_flush_gather(g);   // behind the broadcast on the collectives' stream
 }
 
 int vcs_group_encode(vcs_group *g) {
     if (!g) return gfail(nullptr, VCS_E_ARG, "null group");
     if (g->n_p < 0) return gfail(g, VCS_E_STATE, "no GOP layout yet (vcs_group_layout)");
     int rc;
+    if ((rc = group_flush_gather(g))) return rc;   // the previous GOP's vectors
     if (g->gop_prefetched <= g->gop && (rc = vcs_group_prefetch_ref(g))) return rc;
     const int b = (int)(g->gop & 1);
     for (auto &p : g->per) {
@@ -498,37 +540,11 @@ int vcs_group_encode(vcs_group *g) {
         G_HIP(g, hipEventRecord(p.ev_kern[b], c->stream));
         p.kern_rec[b] = true;
     }
-    // ---- motion-vector collection ---------------------------------------------------
-    if (g->rccl) {
-        for (auto &p : g->per) {
-            G_HIP(g, hipSetDevice(p.c->device));
-            if (p.cs != p.c->stream) G_HIP(g, hipStreamWaitEvent(p.cs, p.ev_kern[b], 0));
-        }
-        G_NCCL(g, ncclGroupStart());
-        for (auto &p : g->per) {
-            hipSetDevice(p.c->device);
-            ncclResult_t r = ncclAllGather(p.stage[b], p.all[b], g->chunk, ncclUint8, p.comm, p.cs);
-            if (r != ncclSuccess) {
-                ncclGroupEnd();
-                return gfail(g, VCS_E_COMM, "ncclAllGather failed: %s", ncclGetErrorString(r));
-            }
-        }
-        G_NCCL(g, ncclGroupEnd());
-    } else {
-        for (size_t i = 0; i < g->per.size(); i++) {
-            auto &p = g->per[i];
-            G_HIP(g, hipSetDevice(p.c->device));
-            if (p.cs != p.c->stream) G_HIP(g, hipStreamWaitEvent(p.cs, p.ev_kern[b], 0));
-            for (auto &q : g->per)
-                G_HIP(g, hipMemcpyAsync(q.all[b] + (size_t)(g->rank0 + i) * g->chunk, p.stage[b], g->chunk,
-                                        hipMemcpyDeviceToDevice, p.cs));
-        }
-    }
-    for (auto &p : g->per) {
-        G_HIP(g, hipSetDevice(p.c->device));
-        G_HIP(g, hipEventRecord(p.ev_gather[b], p.cs));
-        p.gather_rec[b] = true;
-    }
+    // The all-gather of this GOP's vectors is enqueued LAZILY, by the next group call: a
+    // vcs_group_prefetch_ref that follows puts the next I frame's broadcast IN FRONT of it on
+    // the collectives' stream (the broadcast runs beside this GOP's tail kernel; the gather
+    // has to wait for the tail anyway).  Every process makes the same calls in the same order.
+    g->gather_pending = b;
     g->gop++;
     return VCS_OK;
 }
@@ -546,14 +562,15 @@ int vcs_group_decode(vcs_group *g) {
 
 int vcs_group_sync(vcs_group *g) {
     if (!g) return gfail(nullptr, VCS_E_ARG, "null group");
-    return group_sync_all(g);
+    int rc = group_flush_gather(g);
+    return rc ? rc : group_sync_all(g);
 }
 
 int vcs_group_get_mv(vcs_group *g, int16_t *mv_out, uint32_t *ns_out) {
     if (!g) return gfail(nullptr, VCS_E_ARG, "null group");
     if (g->gop == 0) return gfail(g, VCS_E_STATE, "nothing encoded yet");
-    int rc = group_sync_all(g);
-    if (rc) return rc;
+    int rc = group_flush_gather(g);
+    if (rc || (rc = group_sync_all(g))) return rc;
     const int b = (int)((g->gop - 1) & 1);
     auto &p0 = g->per[0];
     const size_t N = (size_t)p0.c->g.N, Nn = N ? N : 1;
@@ -572,8 +589,8 @@ int vcs_group_get_mv(vcs_group *g, int16_t *mv_out, uint32_t *ns_out) {
 // max over all shards' processes of *v (bench.py's max-over-ranks step time); also a barrier.
 int vcs_group_max_f64(vcs_group *g, double *v) {
     if (!g || !v) return gfail(g, VCS_E_ARG, "null pointer");
-    int rc = group_sync_all(g);
-    if (rc) return rc;
+    int rc = group_flush_gather(g);
+    if (rc || (rc = group_sync_all(g))) return rc;
     if (!g->rccl || g->world == (int)g->per.size()) return VCS_OK;  // one process: nothing to reduce
     auto &p0 = g->per[0];
     G_HIP(g, hipSetDevice(p0.c->device));
