@@ -289,7 +289,11 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 
         // everybody has finished block by-1 (its window rows may be replaced) and the rows
         // parked during block by-1 (or the fill) are visible
+#ifdef VCS_EXP_NOBARRIER   // experiment builds only (results are wrong): what the lock-step costs
+        wave_lds_fence();
+#else
         if (W > 1) wg_lds_barrier(); else wave_lds_fence();
+#endif
         if (roll) {
             // rows B+64 .. B+79 -> ring slots of rows B-16 .. B-1 (read by block by-1 only)
             int ns = Bslot + 64;
@@ -316,9 +320,14 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
             s_d = __builtin_amdgcn_sad_u8(A.rv[q], 0u, s_d);
             s_c = __builtin_amdgcn_sad_u8(A.cv[q], 0u, s_c);
         }
+#ifdef VCS_EXP_NOREDUCE   // experiment builds only (results are wrong): cost of the wave reductions
+        const uint32_t sdiff = 0xFFFFFFFFu;
+        s_c = __builtin_amdgcn_readfirstlane(s_c + s_d);
+#else
         s_d = wave_sum_u32(s_d - s_c);
         s_c = wave_sum_u32(s_c);
         const uint32_t sdiff = s_d >> 1;
+#endif
         const bool is_static = !g.never_static && sdiff <= g.thresh;
         if (is_static && lane == 0) {
             *(uint32_t *)(mv + 2 * oidx) = 0u;
@@ -349,8 +358,14 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 
             uint32_t acc0[4] = {0, 0, 0, 0};
             uint32_t second = 0;
+#ifndef VCS_EXP_NOCORE    // experiment builds only: everything but the comparisons
             me16g_rows<ROWB>(s_win + s0 * ROWB + cj0 * 16, s_cur, acc0);
+#endif
+#ifdef VCS_EXP_NOCORE
+            if (false) {
+#else
             if (ncand > 64) {
+#endif
                 if (ncand == 100)
                     me16g_slabs<ROWB, 5>(s_win, s_cur, s_part, Bslot, 36, ncj, lane);
                 else
@@ -366,7 +381,11 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
             uint32_t key = 0xFFFFFFFFu;
             if (act0) key = (cost0 << 7) | (uint32_t)cand0;
             if (act1) key = min(key, (cost1 << 7) | (uint32_t)cand1);
+#ifdef VCS_EXP_NOREDUCE
+            key = __builtin_amdgcn_readfirstlane(key);
+#else
             key = wave_min_u32(key);
+#endif
             if (lane == 0) {
                 int bx = 0, byy = 0;
                 unsigned long long c = 9999999999ull;
