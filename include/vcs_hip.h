@@ -313,6 +313,12 @@ int vcs_intra_chroma8x8(vcs_ctx *ctx, const uint8_t *Cr, const uint8_t *Cb, doub
  * pins it; exact for integer-valued input.                                      */
 int vcs_intra_transform4x4(vcs_ctx *ctx, const double *res, double *out);
 
+/* 4:2:0 chroma subsampling (next row N4; reference ChromaSubsampling/chroma.py:8-21, a
+ * run-at-import script upstream): BGR -> YCrCb, cv2.boxFilter(ksize=(2,2)) over Cr and Cb,
+ * samples at even rows / columns.  Y (nullable): H x W; cr_s / cb_s: ((H+1)/2) x ((W+1)/2).
+ * OpenCV's box filter is third-party arithmetic restated here: parity unpinned.          */
+int vcs_chroma420(vcs_ctx *ctx, const uint8_t *bgr, uint8_t *Y, uint8_t *cr_s, uint8_t *cb_s);
+
 /* GPU-side ordering against a foreign HIP stream (the stream torch / RCCL
  * collectives run on), without host synchronisation:
  *   vcs_stream_wait:   work enqueued on the context's stream after this call

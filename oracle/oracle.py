@@ -152,6 +152,17 @@ def ycrcb2bgr(ycc):
     return out
 
 
+def chroma420(bgr):
+    """chroma.py:8-21 (boxFilter restated; parity unpinned): (Y, Cr samples, Cb samples)."""
+    bgr = _c(bgr, np.uint8)
+    H, W = bgr.shape[:2]
+    Y = np.zeros((H, W), np.uint8)
+    cr = np.zeros(((H + 1) // 2, (W + 1) // 2), np.uint8)
+    cb = np.zeros_like(cr)
+    lib().vcso_chroma420(_p(bgr, _u8p), H, W, _p(Y, _u8p), _p(cr, _u8p), _p(cb, _u8p))
+    return Y, cr, cb
+
+
 def dct_matrix(n=8):
     D = np.zeros((n, n), np.float64)
     lib().vcso_dct_matrix(n, _p(D, _f64p))

@@ -282,6 +282,39 @@ void vcso_ycrcb2bgr(const uint8_t *ycc, size_t npx, uint8_t *bgr) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* 4:2:0 chroma subsampling, ChromaSubsampling/chroma.py:8-21: cvtColor, then
+ * cv2.boxFilter(plane, ddepth=-1, ksize=(2,2)) and [::2, ::2].  boxFilter restated from
+ * OpenCV 4.x (third party, unpinned): anchor (1,1) -> output (y,x) covers rows y-1..y and
+ * columns x-1..x; BORDER_REFLECT_101 (index -1 -> 1); normalised: sum * 0.25 through
+ * saturate_cast<uchar>(double) = rint (half to even).                                  */
+int vcso_chroma420(const uint8_t *bgr, int H, int W, uint8_t *Y, uint8_t *crs, uint8_t *cbs) {
+    const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;
+    for (int i = 0; i < Hc; i++)
+        for (int j = 0; j < Wc; j++) {
+            int scr = 0, scb = 0;
+            for (int dy = -1; dy <= 0; dy++)
+                for (int dx = -1; dx <= 0; dx++) {
+                    int y = 2 * i + dy, x = 2 * j + dx;
+                    if (y < 0) y = H > 1 ? 1 : 0;
+                    if (x < 0) x = W > 1 ? 1 : 0;
+                    uint8_t ycc[3];
+                    vcso_bgr2ycrcb_px(bgr + ((size_t)y * W + x) * 3, ycc);
+                    scr += ycc[1];
+                    scb += ycc[2];
+                }
+            crs[(size_t)i * Wc + j] = (uint8_t)nearbyint(scr * 0.25);
+            cbs[(size_t)i * Wc + j] = (uint8_t)nearbyint(scb * 0.25);
+        }
+    if (Y)
+        for (size_t p = 0; p < (size_t)H * W; p++) {
+            uint8_t ycc[3];
+            vcso_bgr2ycrcb_px(bgr + 3 * p, ycc);
+            Y[p] = ycc[0];
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* DCTcompressor.py:124-133 (_dctMatrix), same expression order as the Python
  * (math.sqrt / math.cos are libm sqrt / cos).                               */
 void vcso_dct_matrix(int n, double *D) {

@@ -276,3 +276,33 @@ def test_extension_searches_vs_oracle(vh, oracle, search, cost, capsys):
         hit = float((np.array(mv) == [11, -7]).all(axis=1).mean())
         assert hit > 0.25, hit
     capsys.readouterr()
+
+
+def test_chroma420_vs_oracle(vh, oracle):
+    """4:2:0 chroma subsampling (chroma.py:8-21; next row N4): kernel vs the oracle's
+    restatement of cvtColor + cv2.boxFilter(ksize=(2,2)) + [::2, ::2] (parity unpinned: OpenCV
+    is not available), even / odd sizes, extremes, 1080p, and the drop-in function."""
+    rng = np.random.default_rng(7)
+    for H, W in ((8, 8), (7, 10), (33, 17), (64, 96), (1, 5), (6, 1), (1080, 1920)):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        if H >= 8:
+            img[:4] = 255
+            img[-2:] = 0
+        with vh.Context(H, W, 8) as c:
+            Y, cr, cb = c.chroma420(img)
+            oY, ocr, ocb = oracle.chroma420(img)
+            assert np.array_equal(Y, oY) and np.array_equal(cr, ocr) and np.array_equal(cb, ocb), (H, W)
+            assert cr.shape == ((H + 1) // 2, (W + 1) // 2)
+            _, cr2, _ = c.chroma420(img, want_y=False)
+            assert np.array_equal(cr2, ocr)
+    sys_path = __import__("sys").path
+    cdir = __import__("os").path.join(__import__("conftest").PKG, "ChromaSubsampling")
+    if cdir not in sys_path:
+        sys_path.insert(0, cdir)
+    import chroma as CH
+    img = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    out = CH.subsample420(img)
+    want = oracle.chroma420(img)
+    assert len(out) == 3 and all(np.array_equal(a, b) for a, b in zip(out, want))
+    with pytest.raises(TypeError):
+        CH.subsample420(img.astype(np.float32))

@@ -149,3 +149,21 @@ def test_intra_transform4x4_matches_numpy(oracle):
             t = np.matmul(C, X[i:i + 4, j:j + 4])
             want[i:i + 4, j:j + 4] = np.round(np.matmul(t, C.transpose()))
     assert np.array_equal(oracle.intra_transform4x4(X), want)
+
+
+def test_chroma420_matches_numpy_restatement(oracle):
+    """vcso_chroma420 (chroma.py:8-21) against the same definition written with NumPy: reflect-101
+    padding on the top / left, 2x2 sums, sum * 0.25 rounded half to even, [::2, ::2]."""
+    rng = np.random.default_rng(5)
+    for H, W in ((7, 10), (16, 16), (2, 4), (5, 2), (33, 18)):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        Y, cr, cb = oracle.chroma420(img)
+        ycc = oracle.bgr2ycrcb(img)
+
+        def box(pl):
+            P = np.pad(pl.astype(np.int64), ((1, 0), (1, 0)), mode="reflect")
+            s = P[:-1, :-1] + P[:-1, 1:] + P[1:, :-1] + P[1:, 1:]
+            return np.rint(s * 0.25).astype(np.uint8)
+        assert np.array_equal(Y, ycc[..., 0])
+        assert np.array_equal(cr, box(ycc[..., 1])[::2, ::2]), (H, W)
+        assert np.array_equal(cb, box(ycc[..., 2])[::2, ::2]), (H, W)

@@ -379,6 +379,55 @@ __global__ __launch_bounds__(64) void k_mc(const uint8_t *__restrict__ ref,
     }
 }
 
+// 4:2:0 chroma subsampling (reference ChromaSubsampling/chroma.py:8-21):
+// BGR -> YCrCb (the same 8-bit conversion as k_fdct), a normalised 2x2 box filter over Cr and
+// Cb as cv2.boxFilter(ksize=(2, 2)) computes it -- anchor (1, 1): output (y, x) averages rows
+// y-1..y and columns x-1..x, BORDER_REFLECT_101 (index -1 -> 1), sum * 0.25 rounded half to
+// even -- and the samples at even rows / columns (`[::2, ::2]`).  Third-party semantics
+// restated from OpenCV 4.x (parity unpinned, like cvtColor).  One thread per chroma sample;
+// the full-resolution Y plane is written by the threads that own its four pixels.
+__global__ __launch_bounds__(256) void k_chroma420(const uint8_t *__restrict__ bgr, int H, int W,
+                                                   uint8_t *__restrict__ Yp, uint8_t *__restrict__ crs,
+                                                   uint8_t *__restrict__ cbs) {
+    const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Hc * Wc) return;
+    const int i = idx / Wc, j = idx - i * Wc;
+    const size_t pitch = (size_t)3 * W;
+    int scr = 0, scb = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 0; dy++)
+#pragma unroll
+        for (int dx = -1; dx <= 0; dx++) {
+            int y = 2 * i + dy, x = 2 * j + dx;
+            y = y < 0 ? min(1, H - 1) : y;   // reflect-101 (a 1-pixel-high image repeats its row)
+            x = x < 0 ? min(1, W - 1) : x;
+            const uint8_t *p = bgr + (size_t)y * pitch + (size_t)(3 * x);
+            int Yv, Cr, Cb;
+            bgr2ycc(p[0], p[1], p[2], Yv, Cr, Cb);
+            scr += Cr;
+            scb += Cb;
+        }
+    // sum / 4 rounded half to even: sums with remainder 2 go to the even neighbour
+    auto rne4 = [](int s) { const int q = s >> 2, r = s & 3; return q + (r == 3 || (r == 2 && (q & 1))); };
+    crs[idx] = (uint8_t)rne4(scr);
+    cbs[idx] = (uint8_t)rne4(scb);
+    if (Yp) {
+#pragma unroll
+        for (int dy = 0; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = 0; dx <= 1; dx++) {
+                const int y = 2 * i + dy, x = 2 * j + dx;
+                if (y < H && x < W) {
+                    const uint8_t *p = bgr + (size_t)y * pitch + (size_t)(3 * x);
+                    int Yv, Cr, Cb;
+                    bgr2ycc(p[0], p[1], p[2], Yv, Cr, Cb);
+                    Yp[(size_t)y * W + x] = (uint8_t)Yv;
+                }
+            }
+    }
+}
+
 // MotionProcessor.get_residuals (motion.py:38-40) and the decoder's wrap-add
 // (decoder.py:57,60): out = a -/+ b per byte; 16 bytes per lane per step.
 template <int SIGN>

@@ -1306,6 +1306,27 @@ int vcs_intra_transform4x4(vcs_ctx *c, const double *res, double *out) {
     return VCS_OK;
 }
 
+int vcs_chroma420(vcs_ctx *c, const uint8_t *bgr, uint8_t *Y, uint8_t *cr_s, uint8_t *cb_s) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!bgr || !cr_s || !cb_s) return fail(c, VCS_E_ARG, "null pointer");
+    const int H = c->g.H, W = c->g.W, Hc = (H + 1) / 2, Wc = (W + 1) / 2;
+    const size_t nc = (size_t)Hc * Wc, hw = (size_t)H * W;
+    // d_a: the frame; d_b: Y plane (H*W) then the two sample planes (2 * nc <= 2 * F / 3 ... fits F)
+    uint8_t *dY = c->d_b, *dcr = c->d_b + hw, *dcb = dcr + nc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_a, bgr, c->F, hipMemcpyHostToDevice, c->stream));
+    EvPair ev;
+    if ((rc = t_begin(c, VCS_T_AUX, &ev))) return rc;
+    hipLaunchKernelGGL(k_chroma420, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, c->stream, c->d_a, H,
+                       W, Y ? dY : (uint8_t *)nullptr, dcr, dcb);
+    if ((rc = t_end(c, &ev))) return rc;
+    if (Y) HIP_TRY(c, hipMemcpyAsync(Y, dY, hw, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cr_s, dcr, nc, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cb_s, dcb, nc, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
 int vcs_stream_wait(vcs_ctx *c, void *foreign_stream) {
     int rc = use(c);
     if (rc) return rc;

@@ -94,6 +94,7 @@ SIGNATURES = {
     "vcs_intra_luma16x16": (ctypes.c_int, [_c_ctx, _u8p, _f64p, _f64p, _f64p]),
     "vcs_intra_chroma8x8": (ctypes.c_int, [_c_ctx, _u8p, _u8p, _f64p, _f64p, _f64p, _f64p, _f64p]),
     "vcs_intra_transform4x4": (ctypes.c_int, [_c_ctx, _f64p, _f64p]),
+    "vcs_chroma420": (ctypes.c_int, [_c_ctx, _u8p, _u8p, _u8p, _u8p]),
     "vcs_stream_wait": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_signal": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_handle": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_void_p)]),
@@ -469,6 +470,17 @@ class Context:
         self._ck(self._lib.vcs_intra_transform4x4(self._h, res.ctypes.data_as(_f64p),
                                                   out.ctypes.data_as(_f64p)))
         return out
+
+    def chroma420(self, bgr, want_y=True):
+        """4:2:0 subsampling of a BGR frame (chroma.py:8-21): (Y or None, Cr samples, Cb samples)."""
+        bgr = _frame(bgr, self.shape, "image")
+        hc, wc = (self.H + 1) // 2, (self.W + 1) // 2
+        Y = np.zeros((self.H, self.W), np.uint8) if want_y else None
+        cr, cb = np.zeros((hc, wc), np.uint8), np.zeros((hc, wc), np.uint8)
+        self._ck(self._lib.vcs_chroma420(self._h, bgr.ctypes.data_as(_u8p),
+                                         Y.ctypes.data_as(_u8p) if want_y else None,
+                                         cr.ctypes.data_as(_u8p), cb.ctypes.data_as(_u8p)))
+        return Y, cr, cb
 
     # -- GOP path -----------------------------------------------------------
     def gop_reserve(self, n_slots, with_decode=False):
