@@ -716,8 +716,8 @@ int vcs_wait(vcs_ctx *c, int slot, int16_t *mv_out, uint32_t *n_static) {
     if (slot < 0 || slot >= (int)c->aslots.size()) return fail(c, VCS_E_ARG, "bad slot %d", slot);
     auto &s = c->aslots[slot];
     if (!s.busy) return fail(c, VCS_E_STATE, "slot %d has nothing in flight", slot);
+    s.busy = false;   // whatever happens, the slot is handed back
     HIP_TRY(c, hipEventSynchronize(s.ev_out));
-    s.busy = false;
     const size_t N = c->g.N;
     if (mv_out && N) memcpy(mv_out, s.h_mv, N * 4);
     if (n_static) memcpy(n_static, s.h_mv + (N ? N : 1) * 2, 4);

@@ -273,6 +273,10 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            grp = getattr(self, "_group", None)
+            grp = grp() if grp is not None else None
+            if grp is not None:          # vcs_ctx_destroy takes the group with it: drop the stale handle
+                grp._g = _vp()
             self._lib.vcs_ctx_destroy(self._h)
             self._h = _c_ctx()
 
@@ -630,6 +634,9 @@ class Group:
         self.world, self.rank0, self.n_local, self.transport = w.value, r0.value, nl.value, tr.value
         self.N = self.contexts[0].N
         self.n_p = None
+        import weakref
+        for c in self.contexts:
+            c._group = weakref.ref(self)
 
     @classmethod
     def from_rank(cls, ctx, unique_id, world, rank):
@@ -643,13 +650,14 @@ class Group:
 
     def _ck(self, rc):
         if rc:
-            raise VcsError(rc, (self._lib.vcs_group_last_error(self._g) or b"").decode())
+            raise VcsError(rc, (self._lib.vcs_group_last_error(self._g if self._g.value else None) or b"").decode())
 
     def close(self):
         if getattr(self, "_g", None) is not None and self._g.value:
-            if all(getattr(c, "_h", None) is not None and c._h.value for c in self.contexts):
-                self._lib.vcs_group_destroy(self._g)   # (a destroyed context took the group with it)
+            self._lib.vcs_group_destroy(self._g)   # (Context.close clears _g when it takes the group down)
             self._g = _vp()
+        for c in self.contexts:
+            c._group = None
 
     def __del__(self):
         try:
