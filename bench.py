@@ -230,7 +230,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements (one-GOP loop, host path, parity, bandwidth)")
     ap.add_argument("--with-decode", action="store_true",
-                    help="also time the decode kernel over the GOP (reported next to the line)")
+                    help="also time the decode kernel over the GOP even with --no-extras (it is part of "
+                         "the default secondary measurements)")
     ap.add_argument("--intra", action="store_true",
                     help="BASELINE config 5 instead: the intra-prediction kernels on a 1080p I frame")
     ap.add_argument("--same-ref", action="store_true",
@@ -247,6 +248,7 @@ def main():
     n_local = 1 if world > 1 else max(1, args.gpus)
     n_gpus = world if world > 1 else n_local
     use_group = args.group or n_gpus > 1
+    args.with_decode = args.with_decode or not args.no_extras   # second line of SURVEY 8d
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a
     # version banner), so file descriptor 1 is pointed at stderr for the whole run and the
     # line goes to a private copy of the original stdout.
@@ -490,16 +492,19 @@ def main():
             # second line of SURVEY 8d: dequantise + IDCT + colour + MC-add over the same GOP
             ctx.timing_enable(True)
             ctx.timing_reset()
-            for _ in range(5):
-                ctx.gop_decode(slot0, n0)
+            for k in range(6):                      # the sets in turn: planes read cold, like the encode
+                ctx.gop_decode((k % sets) * n0, n0)
             ms2, l2 = ctx.timing()
             ctx.timing_enable(False)
             dec_ms = ms2[vcs_hip.T_DEC] / max(1, int(l2[vcs_hip.T_DEC]))
             alg = (9 * F + 4 * N + F) * n0  # planes + ref + vectors in, frame out
             out["decode"] = {"kernel": "k_idct<residual>", "avg_launch_ms": round(dec_ms, 4),
                              "achieved_gbs": round(alg / (dec_ms * 1e-3) / 1e9, 1),
+                             "hbm_frac": round(alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "encode_plus_decode_macroblocks_per_ms":
-                                 round(n0 * N / (dt / args.steps * 1e3 + dec_ms), 1)}
+                                 round(n0 * N / (dt / args.steps * 1e3 + dec_ms), 1),
+                             "what": "dequantise + IDCT + colour + MC add over GPU 0's %d frames, kernel only "
+                                     "(SURVEY 8d, second line); every set was encoded before" % n0}
         if not args.no_extras:
             try:
                 out["parity"] = parity_columns(ctx, ref, local_frames[0], mv0, slot0, bs)
