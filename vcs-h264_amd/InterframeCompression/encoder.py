@@ -15,6 +15,7 @@ view that downloads on first access, and the drop-in Decoder decodes straight
 from HBM -- the 8x-frame-size planes never cross PCIe; Frame.mv and Frame.c are
 then list-like views of integer arrays (frame.RowList) instead of N Python lists.
 """
+import itertools
 import os
 import math
 
@@ -26,12 +27,16 @@ from motion import MotionProcessor, _as_frame
 from _runtime import ensure_q, ensure_ref, flush_async, invalidate_ref, submit_async
 
 
+_SERIAL = itertools.count(1)   # names an Encoder for good (id() values are recycled)
+
+
 class Encoder:
 
     def __init__(self, pattern, shape, block_size, with_DCT, *, dct_block_size=None, device=0,
                  resident=None, async_slots=None):
         self.ref_frames = []
         self.encoded_frames = []
+        self._serial = next(_SERIAL)
         self.pattern = pattern
         self.ENCODING_PATTERN_LENGTH = len(pattern)
         self.MotionProcessor = MotionProcessor(block_size=block_size, shape=shape, device=device)
@@ -104,10 +109,10 @@ class Encoder:
         if self.with_DCT:
             dc._check(mp.shape[0], mp.shape[1])
         ctx = mp._ctx()
-        # resident mode: the I frame is identified by (this encoder, its index) -- no per-frame
+        # resident mode: the I frame is identified by (this encoder's serial, its index) -- no per-frame
         # hashing of 6-25 MB; default mode: full hash (the caller's array is aliased, encoder.py:42)
         ensure_ref(ctx, _as_frame(ref, mp.shape, "ref_frame"),
-                   generation=(id(self), ref_idx) if self.resident else None)
+                   generation=(self._serial, ref_idx) if self.resident else None)
         if self.with_DCT:
             ensure_q(ctx, dc.Q, dc.coeff_mode)
         keep = self.with_DCT and self.resident
