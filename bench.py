@@ -164,6 +164,43 @@ def host_path(H, W, bs, ref, frames, device, n_frames=48):
     return out
 
 
+def coeff_modes(H, W, bs, ref, frames, device, steps=8):
+    """the same GOP step with float32 planes and with rounded int16 levels
+    (np.round of the reference's quotient): the output stream shrinks 2x / 4x."""
+    import vcs_hip
+    out = {}
+    n = len(frames)
+    N = (H // bs) * (W // bs)
+    F = 3 * H * W
+    for name, mode, per_px in (("f32", vcs_hip.VCS_COEFF_F32, 4), ("i16_rounded", vcs_hip.VCS_COEFF_I16, 2)):
+        with vcs_hip.Context(H, W, bs, 8, device=device) as c:
+            c.set_params(coeff_mode=mode)
+            c.set_ref(ref)
+            c.gop_reserve(2 * n)
+            c.gop_upload(0, frames)
+            c.gop_upload(n, frames)
+            for k in range(2):
+                c.ref_written()
+                c.gop_encode(k * n, n)
+            c.sync()
+            c.timing_enable(True)
+            c.timing_reset()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                c.ref_written()
+                c.gop_encode((k % 2) * n, n)
+            c.sync()
+            dt = (time.perf_counter() - t0) / steps
+            ms, l = c.timing()
+            tail = ms[vcs_hip.T_ENC_TAIL] / max(1, int(l[vcs_hip.T_ENC_TAIL]))
+            alg = ((2 + per_px) * F + 4 * N) * n
+            out[name] = {"value": round(n * N / dt / 1e3, 1), "unit": "macroblocks/ms",
+                         "ms_per_step": round(dt * 1e3, 4), "enc_tail_ms": round(tail, 4),
+                         "enc_tail_gbs": round(alg / (tail * 1e-3) / 1e9, 1)}
+    out["note"] = "two resident GOP copies in turn; float64 (the reference's type) is the headline"
+    return out
+
+
 def intra_mode(args, real_stdout):
     """BASELINE config 5: intramodes.py 4x4 intra prediction + the 4x4 core
     transform on a 1080p I frame (resized to multiples of 16 as intraframe.py:324 does: 1920 x
@@ -525,6 +562,10 @@ def main():
                 out["host_path"] = host_path(H, W, bs, ref, local_frames[0], devices[0])
             except Exception as e:
                 out["host_path"] = {"error": repr(e)}
+            try:
+                out["coeff_modes"] = coeff_modes(H, W, bs, ref, local_frames[0], devices[0])
+            except Exception as e:
+                out["coeff_modes"] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 

@@ -306,3 +306,28 @@ def test_chroma420_vs_oracle(vh, oracle):
     assert len(out) == 3 and all(np.array_equal(a, b) for a, b in zip(out, want))
     with pytest.raises(TypeError):
         CH.subsample420(img.astype(np.float32))
+
+
+def test_config2_1080p_pair_reference_and_dense_search(vh, oracle):
+    """C2: a synthetic 1080p I+P pair, 8x8 blocks, +-16 px.  The reference's own search at that
+    block size is the stride-3 grid (motion.py:132: round(8/3)); BASELINE's wording "full search"
+    is the dense stride-1 grid over the same window -- both against the oracle, whole frame:
+    vectors, static count, winning costs, then the fused encode and decode on the dense vectors."""
+    from synth import synth_v1
+    H, W, bs = 1080, 1920, 8
+    ref, cur = synth_v1(H, W, seed=1234)
+    with vh.Context(H, W, bs) as c:
+        c.set_ref(ref)
+        for step in (3, 1):
+            c.set_params(step=step)
+            mv, ns, cost = c.me(cur, want_cost=True)
+            omv, ons, ocost = oracle.me(cur, ref, bs, step=step, want_cost=True)
+            assert np.array_equal(mv, omv) and ns == ons, step
+            assert np.array_equal(cost, ocost), step
+        # dense vectors reach every displacement in [-16, 7]: more than the 8 x 8 grid positions
+        assert len(np.unique(mv, axis=0)) > 64
+        mv2, planes, _, _ = c.encode_p(cur)
+        assert np.array_equal(mv2, omv)
+        _, oplanes, _ = oracle.encode_p(cur, ref, bs, step=1)
+        assert np.array_equal(planes.view(np.int64), oplanes.view(np.int64))
+        assert np.array_equal(c.decode_p(mv2, planes), oracle.decode_p(omv, oplanes, ref, bs))
