@@ -10,7 +10,7 @@ for pass in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_W
             "SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_SCA" \
             "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/p$i -- python3 $root/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/p$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/p$i -- python3 $root/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-extras $BENCH_EXTRA > $out/p$i.log 2>&1
 done
 python3 - $out <<'PY' | tee $out/summary.txt
 import csv, glob, sys, collections

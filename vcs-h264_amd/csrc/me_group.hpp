@@ -233,6 +233,7 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 
       int B = max(by0 * BS - WIN, 0);
       int Bslot = B % RING;
+      uint32_t n_static_unit = 0;  // static blocks of this wave's frame in this unit: ONE atomic per unit
       // ---- the segment's first window: rows B .. B+63, cooperatively -----------------
       if (W > 1) wg_lds_barrier();  // everybody is done with the previous unit's window
       {
@@ -329,9 +330,9 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
         const uint32_t sdiff = s_d >> 1;
 #endif
         const bool is_static = !g.never_static && sdiff <= g.thresh;
+        n_static_unit += is_static ? 1u : 0u;
         if (is_static && lane == 0) {
             *(uint32_t *)(mv + 2 * oidx) = 0u;
-            atomicAdd(&n_static[f], 1u);
             if (cost_out) cost_out[oidx] = sdiff;
         }
         if (!is_static) {
@@ -410,6 +411,8 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
         B = Bn;
         A = Bq;
       }
+      // (real video is mostly static blocks: one atomic per block on 29 counters serialises in L2)
+      if (active && n_static_unit && lane == 0) atomicAdd(&n_static[f], n_static_unit);
     }
     if (clk_out && tid == 0) atomicMax(clk_out, __builtin_amdgcn_s_memtime() - clk0);
 }

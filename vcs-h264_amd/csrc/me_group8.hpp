@@ -138,6 +138,7 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
 
       int B = max(by0 * BS - WIN, 0);
       int Bslot = B % RING;
+      uint32_t n_static_unit = 0;  // static blocks of this wave's frame in this unit: ONE atomic per unit
       if (W > 1) wg_lds_barrier();
       {
           const uint32_t wsrc = (uint32_t)(B * g.pitch) + col_off;
@@ -215,9 +216,9 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
         s_c = wave_sum_u32(s_c);
         const uint32_t sdiff = s_d >> 1;
         const bool is_static = !g.never_static && sdiff <= g.thresh;
+        n_static_unit += is_static ? 1u : 0u;
         if (is_static && lane == 0) {
             *(uint32_t *)(mv + 2 * oidx) = 0u;
-            atomicAdd(&n_static[f], 1u);
             if (cost_out) cost_out[oidx] = sdiff;
         }
         if (!is_static) {
@@ -272,6 +273,8 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
         B = Bn;
         A = Bq;
       }
+      // (real video is mostly static blocks: one atomic per block on 29 counters serialises in L2)
+      if (active && n_static_unit && lane == 0) atomicAdd(&n_static[f], n_static_unit);
     }
 }
 
