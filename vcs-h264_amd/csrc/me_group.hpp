@@ -168,6 +168,19 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
     // shader-clock cycles this workgroup lives (s_memtime): the longest-lived workgroup's
     // count over the launch's duration is the clock the chip held under this load
     const unsigned long long clk0 = clk_out ? __builtin_amdgcn_s_memtime() : 0ull;
+#ifdef VCS_EXP_PHASES   // experiment builds only: shader cycles per phase of the block loop -> clk_out[1..8]
+    unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clk0;
+#define VCS_TICK(k)                                                        \
+    do {                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+        ph[k] += t_ - ph_t;                                                \
+        ph_t = t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+    } while (0)
+#else
+#define VCS_TICK(k) do { } while (0)
+#endif
     constexpr int ROWB = kMe16gRowB, RING = kMe16gRing;
     constexpr int BS = 16, WIN = 32, STEP = 5, NG = kMe16Groups;
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe16gWinBytes + W * kMe16gWaveBytes];
@@ -278,8 +291,11 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 
       Me16gRegs<W> A;
       issue(by0, B, A);
+      uint32_t st_mv = 0, st_clo = 0, st_chi = 0;  // lane b: result of block by0 + 64 k + b
+      VCS_TICK(8);  // unit prologue (fill) and the previous unit's epilogue
 
       for (int by = by0; by < by1; by++) {
+        VCS_TICK(7);  // loop end (vmcnt wait, A = Bq)
         const int y = by * BS;
         const bool last = by + 1 == by1;
         const int byn = last ? by : by + 1;
@@ -287,6 +303,7 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
         const bool roll = !last && Bn != B;  // uniform over the workgroup
         Me16gRegs<W> Bq;
         issue(byn, Bn, Bq);
+        VCS_TICK(0);  // issue
 
         // everybody has finished block by-1 (its window rows may be replaced) and the rows
         // parked during block by-1 (or the fill) are visible
@@ -295,6 +312,7 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 #else
         if (W > 1) wg_lds_barrier(); else wave_lds_fence();
 #endif
+        VCS_TICK(1);  // barrier
         if (roll) {
             // rows B+64 .. B+79 -> ring slots of rows B-16 .. B-1 (read by block by-1 only)
             int ns = Bslot + 64;
@@ -311,8 +329,8 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
             }
         }
 
+        VCS_TICK(2);  // roll
         if (active) {
-        const size_t oidx = (size_t)f * g.N + (size_t)(by * g.nbx + bxi);
         // ---- static test (motion.py:109-116), as in k_me16 ---------------------------
         uint32_t s_c = 0, s_d = 0;
 #pragma unroll
@@ -331,10 +349,9 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 #endif
         const bool is_static = !g.never_static && sdiff <= g.thresh;
         n_static_unit += is_static ? 1u : 0u;
-        if (is_static && lane == 0) {
-            *(uint32_t *)(mv + 2 * oidx) = 0u;
-            if (cost_out) cost_out[oidx] = sdiff;
-        }
+        uint32_t mvw = 0u;                 // static block: [0, 0], cost = the difference
+        unsigned long long cw = sdiff;
+        VCS_TICK(3);  // static test
         if (!is_static) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -359,6 +376,7 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 
             uint32_t acc0[4] = {0, 0, 0, 0};
             uint32_t second = 0;
+            VCS_TICK(4);  // current block re-pack, grid
 #ifndef VCS_EXP_NOCORE    // experiment builds only: everything but the comparisons
             me16g_rows<ROWB>(s_win + s0 * ROWB + cj0 * 16, s_cur, acc0);
 #endif
@@ -375,6 +393,7 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
                 second = s_part[min(lane, kMe16Pass2Max - 1)];
             }
 
+            VCS_TICK(5);  // comparisons
             const uint32_t n_lt0 = 768u + 64u - (acc0[0] + acc0[1] + acc0[2] + acc0[3]);
             const uint32_t n_lt1 = 768u + 64u - second;
             const uint32_t cost0 = A.sr[0] + 256u * n_lt0 - s_c;
@@ -387,21 +406,37 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 #else
             key = wave_min_u32(key);
 #endif
-            if (lane == 0) {
+            {
                 int bx = 0, byy = 0;
-                unsigned long long c = 9999999999ull;
+                cw = 9999999999ull;
                 if (key != 0xFFFFFFFFu) {
                     const int cb = (int)(key & 127u);
                     const int cbi = (int)(((uint32_t)cb * inv_ncj) >> 16);
                     byy = i_min + cbi * STEP;
                     bx = j_min + (cb - cbi * ncj) * STEP;
-                    c = key >> 7;
+                    cw = key >> 7;
                 }
-                // one 4-byte store: [dx, dy]
-                *(uint32_t *)(mv + 2 * oidx) = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);
-                if (cost_out) cost_out[oidx] = c;
+                mvw = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);  // [dx, dy]
             }
             wave_lds_fence();  // s_cur / s_part are rewritten by the next block
+        }
+        // Results wait in lane (by - by0) % 64 of a register and leave 64 blocks at a time: a
+        // store inside this loop sits between the prefetch and the s_waitcnt vmcnt(0) that
+        // collects it (gfx9 counts stores in vmcnt), so every block would wait for its own
+        // store to be acknowledged.
+        VCS_TICK(6);  // reduction, result
+        const int slot = (by - by0) & 63;
+        st_mv = lane == slot ? mvw : st_mv;
+        if (cost_out) {
+            st_clo = lane == slot ? (uint32_t)cw : st_clo;
+            st_chi = lane == slot ? (uint32_t)(cw >> 32) : st_chi;
+        }
+        if (slot == 63 || last) {
+            if (lane <= slot) {
+                const size_t o = (size_t)f * g.N + (size_t)((by - slot + lane) * g.nbx + bxi);
+                *(uint32_t *)(mv + 2 * o) = st_mv;
+                if (cost_out) cost_out[o] = (unsigned long long)st_clo | ((unsigned long long)st_chi << 32);
+            }
         }
         }  // active
         if (Bn != B) {
@@ -415,6 +450,11 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
       if (active && n_static_unit && lane == 0) atomicAdd(&n_static[f], n_static_unit);
     }
     if (clk_out && tid == 0) atomicMax(clk_out, __builtin_amdgcn_s_memtime() - clk0);
+#ifdef VCS_EXP_PHASES
+    if (clk_out && lane == 0)
+        for (int k = 0; k < 9; k++) atomicAdd(&clk_out[1 + k], ph[k]);
+#endif
+#undef VCS_TICK
 }
 
 // VCS_ME16_GROUP: frames per workgroup of the shared-window kernel (1, 2, 4, 8; default 4);

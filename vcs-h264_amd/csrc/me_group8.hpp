@@ -75,6 +75,10 @@ struct Me8gRegs {
     uint4 nw[Me8gCfg<W>::kNewN];
 };
 
+#ifdef VCS_EXP_PHASES   // experiment builds only: shader cycles per phase of the block loop
+__device__ unsigned long long g_me8_phases[16];
+#endif
+
 template <int W, int WPS>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
@@ -82,6 +86,19 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
             int16_t *__restrict__ mv, uint32_t *__restrict__ n_static,
             unsigned long long *__restrict__ cost_out) {
     using Cfg = Me8gCfg<W>;
+#ifdef VCS_EXP_PHASES
+    unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+#define VCS_TICK(k)                                                        \
+    do {                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();        \
+        ph[k] += t_ - ph_t;                                                \
+        ph_t = t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+    } while (0)
+#else
+#define VCS_TICK(k) do { } while (0)
+#endif
     constexpr int ROWB = kMe8RowB, RING = kMe8gRing, NG = kMe8Groups;
     constexpr int BS = 8, WIN = 16, STEP = 3;
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe8gWinBytes + W * kMe8gWaveBytes];
@@ -176,17 +193,35 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
 
       Me8gRegs<W> A;
       issue(by0, B, A);
+      uint32_t st_mv = 0, st_clo = 0, st_chi = 0;  // lane b: result of block by0 + 64 k + b
+      VCS_TICK(8);
+#ifdef VCS_EXP_PF2   // experiment builds only: per-block loads two blocks ahead
+      Me8gRegs<W> Bq;
+      { const int b1 = min(by0 + 1, by1 - 1); issue(b1, max(b1 * BS - WIN, 0), Bq); }
+#endif
 
       for (int by = by0; by < by1; by++) {
+        VCS_TICK(7);
         const int y = by * BS;
         const bool last = by + 1 == by1;
         const int byn = last ? by : by + 1;
         const int Bn = max(byn * BS - WIN, 0);
         const bool roll = !last && Bn != B;
+#ifdef VCS_EXP_PF2
+        Me8gRegs<W> Cq;
+        { const int b2 = min(by + 2, by1 - 1); issue(b2, max(b2 * BS - WIN, 0), Cq); }
+#else
         Me8gRegs<W> Bq;
         issue(byn, Bn, Bq);
+#endif
 
+        VCS_TICK(0);
+#ifdef VCS_EXP_NOBARRIER   // experiment builds only (results are wrong): what the lock-step costs
+        wave_lds_fence();
+#else
         if (W > 1) wg_lds_barrier(); else wave_lds_fence();
+#endif
+        VCS_TICK(1);
         if (roll) {
             int ns = Bslot + kMe8Rows;
             ns -= ns >= RING ? RING : 0;  // a multiple of 8: the 8 rows never wrap
@@ -203,8 +238,8 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
             }
         }
 
+        VCS_TICK(2);
         if (active) {
-        const size_t oidx = (size_t)f * g.N + (size_t)(by * g.nbx + bxi);
         // ---- static test (motion.py:109-116) over the 48 dwords of the block ------
         uint32_t s_c = 0, s_d = 0;
         if (lane < 48) {
@@ -217,10 +252,9 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
         const uint32_t sdiff = s_d >> 1;
         const bool is_static = !g.never_static && sdiff <= g.thresh;
         n_static_unit += is_static ? 1u : 0u;
-        if (is_static && lane == 0) {
-            *(uint32_t *)(mv + 2 * oidx) = 0u;
-            if (cost_out) cost_out[oidx] = sdiff;
-        }
+        uint32_t mvw = 0u;                 // static block: [0, 0], cost = the difference
+        unsigned long long cw = sdiff;
+        VCS_TICK(3);
         if (!is_static) {
             s_cur[cur_dst] = ~A.cq | cur_padm;  // negated current block, pad / foreign bytes -> 0xFF
             wave_lds_fence();
@@ -240,30 +274,50 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
             Me8Q a, c;
             me8_ld(c, s_cur);
             me8_ld(a, p);
+            VCS_TICK(4);
+#ifndef VCS_EXP_NOCORE   // experiment builds only (results are wrong): everything but the comparisons
 #pragma unroll
             for (int k = 0; k < BS - 1; k++)
                 me8g_step<true>(a, c, p + (k + 1) * ROWB, s_cur + (k + 1) * 12, cnt);
             me8g_step<false>(a, c, nullptr, nullptr, cnt);
+#else
+            cnt[0] = a.q0.x ^ c.q0.x;
+#endif
 
+            VCS_TICK(5);
             // cost = sum(r) - sum(c) + 256 * #{r < c}; 64 pad bytes always counted
             const uint32_t n_lt = 192u + 64u - (cnt[0] + cnt[1]);
             const uint32_t cost = A.sr + 256u * n_lt - s_c;
             uint32_t key = act ? ((cost << 7) | (uint32_t)lane) : 0xFFFFFFFFu;  // motion.py:149
             key = wave_min_u32(key);
-            if (lane == 0) {
-                int bx = 0, byy = 0;                    // motion.py:102
-                unsigned long long cc = 9999999999ull;  // motion.py:120
+            {
+                int bx = 0, byy = 0;   // motion.py:102
+                cw = 9999999999ull;    // motion.py:120
                 if (key != 0xFFFFFFFFu) {
                     const int cb = (int)(key & 127u);
                     const int cbi = (int)(((uint32_t)cb * inv_ncj) >> 16);
                     byy = i_min + cbi * STEP;
                     bx = j_min + (cb - cbi * ncj) * STEP;
-                    cc = key >> 7;
+                    cw = key >> 7;
                 }
-                *(uint32_t *)(mv + 2 * oidx) = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);
-                if (cost_out) cost_out[oidx] = cc;
+                mvw = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);
             }
             wave_lds_fence();  // s_cur is rewritten by the next block
+        }
+        VCS_TICK(6);
+        // results leave 64 blocks at a time (see k_me16g: no store between prefetch and its wait)
+        const int slot = (by - by0) & 63;
+        st_mv = lane == slot ? mvw : st_mv;
+        if (cost_out) {
+            st_clo = lane == slot ? (uint32_t)cw : st_clo;
+            st_chi = lane == slot ? (uint32_t)(cw >> 32) : st_chi;
+        }
+        if (slot == 63 || last) {
+            if (lane <= slot) {
+                const size_t o = (size_t)f * g.N + (size_t)((by - slot + lane) * g.nbx + bxi);
+                *(uint32_t *)(mv + 2 * o) = st_mv;
+                if (cost_out) cost_out[o] = (unsigned long long)st_clo | ((unsigned long long)st_chi << 32);
+            }
         }
         }  // active
         if (Bn != B) {
@@ -272,10 +326,18 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
         }
         B = Bn;
         A = Bq;
+#ifdef VCS_EXP_PF2
+        Bq = Cq;
+#endif
       }
       // (real video is mostly static blocks: one atomic per block on 29 counters serialises in L2)
       if (active && n_static_unit && lane == 0) atomicAdd(&n_static[f], n_static_unit);
     }
+#ifdef VCS_EXP_PHASES
+    if (lane == 0)
+        for (int k = 0; k < 9; k++) atomicAdd(&g_me8_phases[1 + k], ph[k]);
+#endif
+#undef VCS_TICK
 }
 
 // VCS_ME8_GROUP: frames per workgroup (1, 2, 4, 8; default 4; 0 = k_me8 only).

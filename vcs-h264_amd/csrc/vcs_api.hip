@@ -671,8 +671,8 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     CREATE_TRY(hipMalloc(&c->d_ref, c->Fs + me_fast_ref_slack(g)));
     CREATE_TRY(hipMemset(c->d_ref, 0, c->Fs + me_fast_ref_slack(g)));
     CREATE_TRY(hipMalloc(&c->d_sums, me_fast_sums_bytes(g)));
-    CREATE_TRY(hipMalloc(&c->d_clk, 16));
-    CREATE_TRY(hipMemset(c->d_clk, 0, 16));
+    CREATE_TRY(hipMalloc(&c->d_clk, 128));
+    CREATE_TRY(hipMemset(c->d_clk, 0, 128));
     CREATE_TRY(hipMalloc(&c->d_cur, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_a, c->Fs));
     CREATE_TRY(hipMalloc(&c->d_b, c->Fs));
@@ -1399,6 +1399,23 @@ int vcs_me_cycles(vcs_ctx *c, uint64_t *cycles, int reset) {
     if (reset) HIP_TRY(c, hipMemset(c->d_clk, 0, 8));
     return VCS_OK;
 }
+
+#ifdef VCS_EXP_PHASES   // experiment builds only (tools/gpu_phases.py)
+extern "C" int vcs_me_phases(vcs_ctx *c, uint64_t *out9) {
+    int rc = use(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->g.bs == 8) {
+        static unsigned long long zero[16] = {0};
+        HIP_TRY(c, hipMemcpyFromSymbol(out9, HIP_SYMBOL(vcs::g_me8_phases), 80));
+        HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(vcs::g_me8_phases), zero, 128));
+        return VCS_OK;
+    }
+    HIP_TRY(c, hipMemcpy(out9, c->d_clk, 80, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemset(c->d_clk, 0, 80));
+    return VCS_OK;
+}
+#endif
 
 int vcs_measure_copy_bw(vcs_ctx *c, size_t bytes, int iters, double *gbps_out) {
     int rc = use(c);
