@@ -201,6 +201,126 @@ def coeff_modes(H, W, bs, ref, frames, device, steps=8):
     return out
 
 
+class _FileSync:
+    """Barrier / all-to-all of small values through files in /dev/shm: ONLY for the bench's
+    fall-back below (the ranks of a launcher job agreeing that RCCL could not be brought up, and
+    the max-over-ranks of the timing when it could not).  Never part of the encode path."""
+
+    def __init__(self, rank, world, tag, timeout_s=60.0):
+        import tempfile
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        self.prefix = os.path.join(base, "vcs_bench_sync_%d_%s_w%d" % (os.getuid(), tag, world))
+        self.rank, self.world, self.seq, self.timeout_s, self.mine = rank, world, 0, timeout_s, []
+
+    def exchange(self, value):
+        """Every rank's `value` (a short string), in rank order."""
+        self.seq += 1
+        path = "%s.%d.%d" % (self.prefix, self.seq, self.rank)
+        with open(path + ".tmp", "w") as f:
+            f.write(value)
+        os.replace(path + ".tmp", path)
+        self.mine.append(path)
+        out, t0 = [], time.time()
+        for r in range(self.world):
+            q = "%s.%d.%d" % (self.prefix, self.seq, r)
+            while True:
+                try:
+                    out.append(open(q).read())
+                    break
+                except OSError:
+                    if time.time() - t0 > self.timeout_s:
+                        raise TimeoutError("rank %d: rank %d never reached sync point %d" % (self.rank, r, self.seq))
+                    time.sleep(0.002)
+        while len(self.mine) > 2:          # everybody has read a file once they have written two more
+            try:
+                os.unlink(self.mine.pop(0))
+            except OSError:
+                pass
+        return out
+
+    def close(self):
+        """Leaves nothing behind: after a last symmetric round every rank drops a marker and
+        goes; rank 0 waits for the markers (so nobody is still reading) and removes the lot."""
+        import glob
+        self.exchange("bye")
+        self.seq += 1
+        open("%s.%d.%d" % (self.prefix, self.seq, self.rank), "w").close()
+        if self.rank:
+            return
+        t0 = time.time()
+        while (not all(os.path.exists("%s.%d.%d" % (self.prefix, self.seq, r)) for r in range(self.world))
+               and time.time() - t0 < self.timeout_s):
+            time.sleep(0.002)
+        for q in glob.glob(self.prefix + ".*"):
+            try:
+                os.unlink(q)
+            except OSError:
+                pass
+
+
+class _ReplicaShards:
+    """The bench's fall-back when the RCCL group of a launcher job cannot be created: every
+    rank still encodes its own chunk of the long GOP's P frames with the same kernels, but the
+    I frame reaches each GPU by its own upload and the vectors stay on their GPUs -- no
+    collective.  The JSON line says so under config.collectives; it is there so that a
+    communication set-up problem costs the exchange step and not the whole measurement."""
+    transport = 0
+    n_local = 1
+    partial = True
+
+    def __init__(self, ctx, rank, world, fsync):
+        import vcs_hip
+        self.ctx, self.rank, self.world, self.fs = ctx, rank, world, fsync
+        self._shard = vcs_hip.shard_frames
+        self.set = 0
+
+    def layout(self, n_p, with_decode=False, sets=1):
+        self.n_p = n_p
+        self.first, self.count = self._shard(n_p, self.world, self.rank)
+        self.ctx.gop_reserve(max(1, sets * self.count), with_decode=with_decode)
+
+    def shard(self, i=0):
+        return self.first, self.count
+
+    def use_set(self, k):
+        self.set = k
+
+    def upload(self, first_p, frames):
+        self.ctx.gop_upload(self.set * self.count + first_p - self.first, frames)
+
+    def set_ref(self, ref):
+        self.ctx.set_ref(ref)
+
+    def prefetch_ref(self):
+        pass
+
+    def encode(self):
+        self.ctx.ref_written()
+        if self.count:
+            self.ctx.gop_encode(self.set * self.count, self.count)
+
+    def sync(self):
+        self.ctx.sync()
+
+    def barrier(self):
+        self.fs.exchange("b")
+
+    def max_over_ranks(self, v):
+        return max(float(x) for x in self.fs.exchange(repr(float(v))))
+
+    def get_mv(self):
+        N = self.ctx.N
+        mv = np.zeros((self.n_p, N, 2), np.int16)
+        ns = np.zeros(self.n_p, np.uint32)
+        if self.count:
+            m, n = self.ctx.gop_get_mv(self.set * self.count, self.count)
+            mv[self.first:self.first + self.count], ns[self.first:self.first + self.count] = m, n
+        return mv, ns
+
+    def close(self):
+        self.fs.close()
+
+
 def intra_mode(args, real_stdout):
     """BASELINE config 5: intramodes.py 4x4 intra prediction + the 4x4 core
     transform on a 1080p I frame (resized to multiples of 16 as intraframe.py:324 does: 1920 x
@@ -306,18 +426,38 @@ def main():
     sets = max(1, args.rotate_sets)
     if world == 1 and vcs_hip.device_count() < n_local:
         sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (n_local, vcs_hip.device_count()))
-    devices = [local_rank] if world > 1 else list(range(n_local))
+    # VCS_BENCH_DEVICE: tests put two ranks on one GPU (RCCL refuses that: the fall-back's trigger)
+    devices = [int(os.environ.get("VCS_BENCH_DEVICE", local_rank))] if world > 1 else list(range(n_local))
     ctxs = [vcs_hip.Context(H, W, bs, 8, device=d) for d in devices]
     ctx = ctxs[0]
     N, F = ctx.N, ctx.F
     n_total = 29 if args.strong else args.frames * n_gpus   # P frames of the (long) GOP
     group = None
+    rccl_failed = None
     launched = "RANK" in os.environ          # under torch.distributed.run (or any launcher)
     if use_group:
         if world > 1 or launched:            # one process per GPU: ncclCommInitRank
-            uid = vcs_hip.rendezvous_unique_id(rank, world)
-            group = vcs_hip.Group.from_rank(ctx, uid, world, rank)
-            group.barrier()
+            err = ""
+            try:
+                uid = vcs_hip.rendezvous_unique_id(rank, world)
+                group = vcs_hip.Group.from_rank(ctx, uid, world, rank)
+                group.barrier()
+            except Exception as e:           # noqa: BLE001 -- anything RCCL / the rendezvous raises
+                err, group = repr(e), None
+            if world > 1:
+                # the ranks agree (through files, RCCL being what is in doubt) whether ALL of them
+                # have a communicator; if not, all take the no-collective fall-back
+                fsync = _FileSync(rank, world, vcs_hip._job_tag())
+                errs = [e for e in fsync.exchange(err) if e]
+                if errs:
+                    if group is not None:
+                        group.close()
+                    group = _ReplicaShards(ctx, rank, world, fsync)
+                    rccl_failed = errs[0][:300]
+                else:
+                    fsync.close()
+            elif err:
+                raise RuntimeError(err)
             vcs_hip.rendezvous_cleanup(rank, world)
         else:
             group = vcs_hip.Group(ctxs)
@@ -408,7 +548,10 @@ def main():
         slot0 = last_set * n_total
         mv0, ns0 = ctx.gop_get_mv(slot0, n_total)
         mv_all, ns_all, count0 = mv0, ns0, n_total
-    searched = 1.0 - float(ns_all.sum()) / max(1, len(ns_all) * N)
+    if getattr(group, "partial", False):     # fall-back: only this rank's vectors are here
+        searched = 1.0 - float(ns0.sum()) / max(1, len(ns0) * N)
+    else:
+        searched = 1.0 - float(ns_all.sum()) / max(1, len(ns_all) * N)
 
     if rank == 0:
         units = n_total * N * args.steps                # macroblocks, whole job
@@ -468,6 +611,9 @@ def main():
                                        % (n_gpus, "one process per GPU" if (world > 1 or (launched and use_group)) else
                                           "one process, one context per GPU" if n_gpus > 1 else "single context")),
                        "collectives": ("none" if group is None else
+                                       "NONE -- FALL-BACK: the RCCL group could not be created (%s); every rank "
+                                       "uploaded the I frame itself and kept its vectors, ranks met through "
+                                       "files" % rccl_failed if rccl_failed else
                                        "in-library RCCL broadcast (I frame) + all-gather (vectors) per GOP: " + transport)},
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "kernel_ms_per_step": {"me": round(ms[vcs_hip.T_ME] / args.steps, 4),

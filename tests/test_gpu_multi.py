@@ -10,6 +10,7 @@ a test box has:
     driver's to run; it is unmeasured here.
 
 Everything is compared with the CPU oracle, bit for bit."""
+import os
 import numpy as np
 import pytest
 
@@ -277,3 +278,31 @@ def test_group_schedules_forced(vh, oracle, serial, monkeypatch):
         finally:
             for c in ctxs:
                 c.close()
+
+
+@pytest.mark.gpu
+def test_bench_rank_path_falls_back_without_rccl(tmp_path):
+    """bench.py's process-per-GPU path when RCCL cannot be brought up: two ranks are put on
+    ONE GPU (RCCL refuses duplicate devices), both must agree on the no-collective fall-back,
+    finish, and say so in the JSON line (the launcher contract: one line from rank 0)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    bench = os.path.join(os.path.dirname(here), "bench.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29671", VCS_BENCH_DEVICE="0", VCS_RENDEZVOUS_TAG="t%d" % os.getpid())
+        procs.append(subprocess.Popen(
+            [sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "256",
+             "--width", "320", "--frames", "3", "--no-extras", "--no-cpu-baseline"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=420) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    assert outs[1][0].strip() == ""
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["config"]["frames_per_step_total"] == 6
+    assert "FALL-BACK" in line["config"]["collectives"]
