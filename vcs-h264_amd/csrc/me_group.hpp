@@ -158,6 +158,11 @@ struct Me16gRegs {
 };
 
 // WPS: waves per SIMD the register budget is held to (a workgroup puts W / 4 waves on each SIMD)
+#ifdef VCS_EXP_PHASES   // experiment builds only: [start, end] of every workgroup on the 100 MHz clock
+__device__ unsigned long long g_me16_wg_t[2 * 4096];
+__device__ unsigned long long g_me16_hw[8 * 4096];   // per wave: HW_ID | XCC_ID << 32
+#endif
+
 template <int W, int WPS>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
@@ -168,7 +173,8 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
     // shader-clock cycles this workgroup lives (s_memtime): the longest-lived workgroup's
     // count over the launch's duration is the clock the chip held under this load
     const unsigned long long clk0 = clk_out ? __builtin_amdgcn_s_memtime() : 0ull;
-#ifdef VCS_EXP_PHASES   // experiment builds only: shader cycles per phase of the block loop -> clk_out[1..8]
+#ifdef VCS_EXP_PHASES   // experiment builds only: shader cycles per phase of the block loop -> clk_out[1..9]
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = clk0;
 #define VCS_TICK(k)                                                        \
     do {                                                                   \
@@ -191,7 +197,10 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
     uint32_t *const s_part = s_cur + 16 * kMe16CurPitch;
 
     // ---- work units: (frame group, column segment, block column); XCD-contiguous chunks so
-    // that the workgroups of one XCD sweep neighbouring columns of the same segment together
+    // that the workgroups of one XCD sweep neighbouring columns of the same segment together.
+    // (A per-XCD unit queue -- workgroups taking the next unit from a counter -- was measured in
+    // round 2 and is not kept: no faster on uniform content, slower on content with static
+    // regions)
     const int nseg = (g.nby + seg_len - 1) / seg_len;
     const int ngroups = (n_frames + W - 1) / W;
     const int per_group = nseg * g.nbx, total = ngroups * per_group;
@@ -453,6 +462,15 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 #ifdef VCS_EXP_PHASES
     if (clk_out && lane == 0)
         for (int k = 0; k < 9; k++) atomicAdd(&clk_out[1 + k], ph[k]);
+    if (lane == 0 && blockIdx.x < 4096) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+        g_me16_hw[8 * blockIdx.x + wave] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_me16_wg_t[2 * blockIdx.x] = wg_t0;
+        g_me16_wg_t[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 #endif
 #undef VCS_TICK
 }

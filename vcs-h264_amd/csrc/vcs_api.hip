@@ -1417,6 +1417,23 @@ extern "C" int vcs_me_phases(vcs_ctx *c, uint64_t *out9) {
 }
 #endif
 
+#ifdef VCS_EXP_PHASES
+extern "C" int vcs_me_wg_times(vcs_ctx *c, uint64_t *out, int n) {
+    int rc = use(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(vcs::g_me16_wg_t), (size_t)n * 16));
+    return VCS_OK;
+}
+extern "C" int vcs_me_wg_hw(vcs_ctx *c, uint64_t *out, int n) {
+    int rc = use(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(vcs::g_me16_hw), (size_t)n * 64));
+    return VCS_OK;
+}
+#endif
+
 int vcs_measure_copy_bw(vcs_ctx *c, size_t bytes, int iters, double *gbps_out) {
     int rc = use(c);
     if (rc) return rc;
