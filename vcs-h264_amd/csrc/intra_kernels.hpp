@@ -219,19 +219,37 @@ __global__ __launch_bounds__(64) void k_intra_chroma8(const uint8_t *__restrict_
     const int cols = W >> 3, rows = H >> 3;
     const int bj = blockIdx.x, j = bj * 8;
     const int lane = threadIdx.x, r = lane >> 3, c = lane & 7;
+    const bool s2 = bj > 0;
+    // Only `ub` depends on the block above; the pixels of the next block are fetched while this
+    // one is decided (the walk is a chain of 134 dependent steps at 1080p: their load latency
+    // was most of the kernel).  Index clamps keep the look-ahead of the last block in bounds.
+    struct Px { int yr, yb, ur, lr, lb; };
+    auto fetch = [&](int bi) {
+        const int i = min(bi, rows - 1) * 8;
+        Px p;
+        p.yr = Cr[(size_t)(i + r) * W + j + c];
+        p.yb = Cb[(size_t)(i + r) * W + j + c];
+        p.ur = Cr[(size_t)max(i - 1, 0) * W + j + c];
+        p.lr = Cr[(size_t)(i + r) * W + max(j - 1, 0)];
+        p.lb = Cb[(size_t)(i + r) * W + max(j - 1, 0)];
+        return p;
+    };
+    Px nx = fetch(0);
     for (int bi = 0; bi < rows; bi++) {
         const int i = bi * 8;
-        const bool s1 = bi > 0, s2 = bj > 0;
+        const bool s1 = bi > 0;
         const size_t o = (size_t)(i + r) * W + j + c;
-        const int yr = Cr[o], yb = Cb[o];
+        const Px px = nx;
+        nx = fetch(bi + 1);
+        const int yr = px.yr, yb = px.yb;
         int ur = 128, ub = 128, lr = 128, lb = 128;
         if (s1) {
-            ur = Cr[(size_t)(i - 1) * W + j + c];
+            ur = px.ur;
             ub = s_ub[c];  // Cbres[i-1, j+c] of the block above (:266)
         }
         if (s2) {
-            lr = Cr[(size_t)(i + r) * W + j - 1];
-            lb = Cb[(size_t)(i + r) * W + j - 1];
+            lr = px.lr;
+            lb = px.lb;
         }
         // sums over the 8 up / 8 left neighbours (ub may be negative: bias it)
         const uint32_t top = r == 0 ? 1u : 0u, lef = c == 0 ? 1u : 0u;
