@@ -22,7 +22,14 @@
 
 namespace vcs {
 
-constexpr int kMe8gRing = 40;
+// blocks per roll of the window: the workgroup meets (one s_barrier) and parks new reference rows
+// once per kMe8gRB blocks, 8 * kMe8gRB rows at a time; between two meetings its waves drift.
+#ifndef VCS_ME8G_RB
+#define VCS_ME8G_RB 2
+#endif
+constexpr int kMe8gRB = VCS_ME8G_RB;
+constexpr int kMe8gLive = kMe8Rows + 8 * (kMe8gRB - 1);   // rows the blocks between two meetings read
+constexpr int kMe8gRing = kMe8gLive + 8 * kMe8gRB;        // + the rows parked for the blocks after the next meeting
 constexpr int kMe8gMirror = 7;
 constexpr int kMe8gWinBytes = (kMe8gRing + kMe8gMirror) * kMe8RowB;
 constexpr int kMe8gWaveBytes = 8 * 48;  // the wave's re-packed current block
@@ -65,14 +72,13 @@ __device__ __forceinline__ void me8g_step(Me8Q &a, Me8Q &c, const void *na, cons
 template <int W>
 struct Me8gCfg {
     static constexpr int kLanes = 64 * W;
-    static constexpr int kNewN = (8 * kMe8Groups + kLanes - 1) / kLanes;           // items per lane per roll
-    static constexpr int kFillN = (kMe8Rows * kMe8Groups + kLanes - 1) / kLanes;   // items per lane per fill
+    static constexpr int kNewN = (8 * kMe8gRB * kMe8Groups + kLanes - 1) / kLanes;  // items per lane per roll
+    static constexpr int kFillN = (kMe8gLive * kMe8Groups + kLanes - 1) / kLanes;   // items per lane per fill
 };
 
 template <int W>
 struct Me8gRegs {
     uint32_t rv, cv, cq, sr;
-    uint4 nw[Me8gCfg<W>::kNewN];
 };
 
 #ifdef VCS_EXP_PHASES   // experiment builds only: shader cycles per phase of the block loop
@@ -99,7 +105,7 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
 #else
 #define VCS_TICK(k) do { } while (0)
 #endif
-    constexpr int ROWB = kMe8RowB, RING = kMe8gRing, NG = kMe8Groups;
+    constexpr int ROWB = kMe8RowB, RING = kMe8gRing, NG = kMe8Groups, RB = kMe8gRB, LIVE = kMe8gLive;
     constexpr int BS = 8, WIN = 16, STEP = 3;
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe8gWinBytes + W * kMe8gWaveBytes];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -131,10 +137,10 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
 #pragma unroll
     for (int t = 0; t < Cfg::kNewN; t++) {
         const int e = tid + Cfg::kLanes * t;
-        const int ec = min(e, 8 * NG - 1), row = ec / NG, gi = ec - row * NG;
+        const int ec = min(e, 8 * RB * NG - 1), row = ec / NG, gi = ec - row * NG;
         o_new_src[t] = (uint32_t)(row * g.pitch + 9 * gi);
-        o_new_dst[t] = (uint32_t)(row * ROWB + gi * 16);
-        o_new_row[t] = e < 8 * NG ? row : 99;
+        o_new_dst[t] = (uint32_t)(gi * 16);
+        o_new_row[t] = e < 8 * RB * NG ? row : 999;
     }
 
     for (int u = xcd * chunk + wi; u < u_end; u += nwg) {
@@ -153,16 +159,16 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
       const uint32_t inv_ncj = ncj ? 65536u / (uint32_t)ncj + 1u : 0u;
       const int lci = (int)(((uint32_t)lane * inv_ncj) >> 16), lcj = lane - lci * ncj;  // this lane's candidate
 
-      int B = max(by0 * BS - WIN, 0);
-      int Bslot = B % RING;
+      const int B0 = max(by0 * BS - WIN, 0);
       uint32_t n_static_unit = 0;  // static blocks of this wave's frame in this unit: ONE atomic per unit
       if (W > 1) wg_lds_barrier();
       {
-          const uint32_t wsrc = (uint32_t)(B * g.pitch) + col_off;
+          const uint32_t wsrc = (uint32_t)(B0 * g.pitch) + col_off;
+          const int Bslot = B0 % RING;
           uint4 stg[Cfg::kFillN];
 #pragma unroll
           for (int q = 0; q < Cfg::kFillN; q++) {
-              const int e = min(tid + Cfg::kLanes * q, kMe8Rows * NG - 1), row = e / NG, gg = e - row * NG;
+              const int e = min(tid + Cfg::kLanes * q, LIVE * NG - 1), row = e / NG, gg = e - row * NG;
               stg[q] = buf_ld128(r_ref, (uint32_t)(row * g.pitch + 9 * gg), wsrc);
           }
 #pragma unroll
@@ -173,69 +179,75 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
               v.w = 0u;
               int slot = Bslot + row;
               slot -= slot >= RING ? RING : 0;
-              if (e < kMe8Rows * NG) {
+              if (e < LIVE * NG) {
                   *(uint4 *)(s_win + slot * ROWB + gg * 16) = v;
                   if (slot < kMe8gMirror) *(uint4 *)(s_win + (slot + RING) * ROWB + gg * 16) = v;
               }
           }
       }
 
-      auto issue = [&](int byy, int Bwin, Me8gRegs<W> &R) {
+      auto issue = [&](int byy, Me8gRegs<W> &R) {
           const uint32_t blk_off = (uint32_t)((byy * BS) * g.pitch + 24 * bxi);
           R.rv = buf_ld32(r_ref, o_blk, blk_off);
           R.cv = buf_ld32(r_cur, o_blk, blk_off);
           R.cq = buf_ld32(r_cur, o_cq, blk_off);  // unaligned dword
           R.sr = buf_ld32(r_sums, (uint32_t)(4 * lane), (uint32_t)((byy * g.nbx + bxi) * (kMe8SumStride * 4)));
-          const uint32_t nsrc = (uint32_t)((Bwin + kMe8Rows) * g.pitch) + col_off;
+      };
+      // rows Rg + LIVE .. Rg + LIVE + 8 RB - 1 of the meeting whose first block has window base Rg
+      uint4 nwq[Cfg::kNewN];
+      auto issue_rows = [&](int Rg) {
+          const uint32_t nsrc = (uint32_t)((Rg + LIVE) * g.pitch) + col_off;
 #pragma unroll
-          for (int t = 0; t < Cfg::kNewN; t++) R.nw[t] = buf_ld128(r_ref, o_new_src[t], nsrc);
+          for (int t = 0; t < Cfg::kNewN; t++) nwq[t] = buf_ld128(r_ref, o_new_src[t], nsrc);
       };
 
       Me8gRegs<W> A;
-      issue(by0, B, A);
+      issue(by0, A);
+      issue_rows(B0);
       uint32_t st_mv = 0, st_clo = 0, st_chi = 0;  // lane b: result of block by0 + 64 k + b
       VCS_TICK(8);
-#ifdef VCS_EXP_PF2   // experiment builds only: per-block loads two blocks ahead
-      Me8gRegs<W> Bq;
-      { const int b1 = min(by0 + 1, by1 - 1); issue(b1, max(b1 * BS - WIN, 0), Bq); }
-#endif
 
       for (int by = by0; by < by1; by++) {
         VCS_TICK(7);
         const int y = by * BS;
         const bool last = by + 1 == by1;
-        const int byn = last ? by : by + 1;
-        const int Bn = max(byn * BS - WIN, 0);
-        const bool roll = !last && Bn != B;
-#ifdef VCS_EXP_PF2
-        Me8gRegs<W> Cq;
-        { const int b2 = min(by + 2, by1 - 1); issue(b2, max(b2 * BS - WIN, 0), Cq); }
-#else
+        const int B = max(y - WIN, 0), Bslot = B % RING;   // this block's window base (motion.py:132-135)
+        const int kk = (by - by0) % RB;                     // position between two meetings
+        const bool meet = kk == 0;
+        const bool park = meet && by + RB < by1;            // somebody comes after the next meeting
         Me8gRegs<W> Bq;
-        issue(byn, Bn, Bq);
-#endif
+        issue(last ? by : by + 1, Bq);
 
         VCS_TICK(0);
+        // Meeting: everybody has finished the blocks before this one (their oldest rows may be
+        // replaced) and the rows parked at the previous meeting (or the fill) are visible.
 #ifdef VCS_EXP_NOBARRIER   // experiment builds only (results are wrong): what the lock-step costs
         wave_lds_fence();
 #else
-        if (W > 1) wg_lds_barrier(); else wave_lds_fence();
+        if (meet) { if (W > 1) wg_lds_barrier(); else wave_lds_fence(); }
 #endif
         VCS_TICK(1);
-        if (roll) {
-            int ns = Bslot + kMe8Rows;
-            ns -= ns >= RING ? RING : 0;  // a multiple of 8: the 8 rows never wrap
+        if (park) {
+            // rows B + LIVE .. B + LIVE + 8 RB - 1 (read after the NEXT meeting) go where the rows
+            // below B were: the ring is LIVE + 8 RB rows, slot = row % RING
+            const int ns = (B + LIVE) % RING;
 #pragma unroll
             for (int q = 0; q < Cfg::kNewN; q++) {
-                uint4 v = A.nw[q];
+                uint4 v = nwq[q];
                 v.z &= 0xFFu;
                 v.w = 0u;
-                if (o_new_row[q] < 8) {
-                    *(uint4 *)(s_win + ns * ROWB + o_new_dst[q]) = v;
-                    if (ns == 0 && o_new_row[q] < kMe8gMirror)
-                        *(uint4 *)(s_win + RING * ROWB + o_new_dst[q]) = v;
+                int slot = ns + o_new_row[q];
+                slot -= slot >= RING ? RING : 0;
+                if (o_new_row[q] < 8 * RB) {
+                    *(uint4 *)(s_win + slot * ROWB + o_new_dst[q]) = v;
+                    if (slot < kMe8gMirror) *(uint4 *)(s_win + (slot + RING) * ROWB + o_new_dst[q]) = v;
                 }
             }
+        }
+        // the rows the meeting after the next one parks: loaded while the last block before it runs
+        if (kk == RB - 1) {
+            const int byg = by + 1;                       // first block after the next meeting
+            if (byg + RB < by1) issue_rows(max(byg * BS - WIN, 0));
         }
 
         VCS_TICK(2);
@@ -320,15 +332,7 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
             }
         }
         }  // active
-        if (Bn != B) {
-            Bslot += BS;
-            Bslot -= Bslot >= RING ? RING : 0;
-        }
-        B = Bn;
         A = Bq;
-#ifdef VCS_EXP_PF2
-        Bq = Cq;
-#endif
       }
       // (real video is mostly static blocks: one atomic per block on 29 counters serialises in L2)
       if (active && n_static_unit && lane == 0) atomicAdd(&n_static[f], n_static_unit);
@@ -352,8 +356,8 @@ inline int me8g_group() {
 inline int me8g_wps() {
     static const int v = [] {
         const char *e = getenv("VCS_ME8_WPS");
-        const int w = e ? atoi(e) : 4;
-        return (w >= 2 && w <= 6) ? w : 4;
+        const int w = e ? atoi(e) : 8;   // 59 VGPRs, 12.6 KB of LDS per workgroup: eight waves per SIMD fit
+        return (w >= 2 && w <= 8) ? w : 8;
     }();
     return v;
 }
@@ -412,6 +416,7 @@ inline int launch_me_group8(const Geom &g, hipStream_t stream, int cus, const ui
     if (w == 2) { if (p <= 3) VCS_ME8G(2, 3); if (p >= 6) VCS_ME8G(2, 6); VCS_ME8G(2, 4); }
     if (w == 8) { if (p <= 3) VCS_ME8G(8, 2); if (p >= 6) VCS_ME8G(8, 6); VCS_ME8G(8, 4); }
     if (p <= 3) VCS_ME8G(4, 3);
+    if (p >= 8) VCS_ME8G(4, 8);
     if (p >= 6) VCS_ME8G(4, 6);
     if (p == 5) VCS_ME8G(4, 5);
     VCS_ME8G(4, 4);

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VCS_HIP_LIB", os.path.join(_HERE, "lib", "libvcs_hip.so"))
+LIB_PATH = os.environ.get("VCS_HIP_LIB") or os.path.join(_HERE, "lib", "libvcs_hip.so")
 
 VCS_COEFF_F64, VCS_COEFF_F32, VCS_COEFF_I16 = 0, 1, 2
 KEEP_THRESH = -(1 << 63)  # VCS_KEEP_THRESH
