@@ -57,9 +57,10 @@ def main(path):
                "under-count applies to this pattern too.  k_fdct's 4-byte-per-lane "
                "pixel loads are uncalibrated: its read figure is an upper bound.  k_fdct's traffic is "
                "below its algorithmic bytes because the latter charge the reference frame once per P "
-               "frame (SURVEY 8d) while the band-per-XCD strip mapping keeps it in L2.  k_me16g's WRITE_SIZE "
-               "is mostly its scratch backing store (30 spilled registers of the 128-VGPR build, written "
-               "once per wave in the prologue), not results: the vectors are 0.93 MB per launch."
+               "frame (SURVEY 8d) while neighbouring strips share it in L2.  k_me16g's WRITE_SIZE "
+               "is mostly its scratch backing store (12 spilled registers of the 128-VGPR build: 48 B x 64 "
+               "lanes x 4,096 waves = 12.6 MB, written once per wave in the unit prologue), not results: "
+               "the vectors are 0.93 MB per launch.  The strips of k_fdct are dealt in raster order."
                % sampled,
         "source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)) + "/.."),
         "kernels": kernels,
