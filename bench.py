@@ -146,8 +146,10 @@ def host_path(H, W, bs, ref, frames, device, n_frames=48):
         with contextlib.redirect_stdout(sink):   # encode_frame prints like the reference
             enc.encode_frame(ring[0], 0)
             run(1, 5, False)                     # warm
-            per_frame, done = run(6, n_frames, False)
-            per_frame_prod, _ = run(6 + n_frames, n_frames, True)
+            # steady state: the better of two passes (a pass that has to grow the device heap for
+            # its plane slabs pays tens of milliseconds once)
+            per_frame, done = min(run(6, n_frames, False), run(6 + n_frames, n_frames, False))
+            per_frame_prod, _ = run(6 + 2 * n_frames, n_frames, True)
         N = (H // bs) * (W // bs)
         res[label] = {"encode_frame_ms": round(per_frame * 1e3, 4),
                       "with_producer_copy_ms": round(per_frame_prod * 1e3, 4),
