@@ -105,6 +105,7 @@ struct vcs_ctx {
     std::vector<EvPair> pool;
     double acc_ms[VCS_T_COUNT] = {0, 0, 0, 0};
     uint64_t launches[VCS_T_COUNT] = {0, 0, 0, 0};
+    bool t_no_count = false;   // a later sub-batch of one vcs_gop_encode call: time it, do not count it
     std::string err;
 };
 
@@ -202,7 +203,7 @@ void refresh_q(vcs_ctx *c) {
 // timestamps of that one kernel's dispatch packet -- no extra packets, and exactly the
 // kernel's duration.  With timing off both are no-ops and ev->a / ev->b stay null.
 int t_begin(vcs_ctx *c, int slot, EvPair *ev, bool attach = false) {
-    c->launches[slot]++;
+    if (!c->t_no_count) c->launches[slot]++;
     ev->a = ev->b = nullptr;
     ev->attached = attach;
     if (!c->timing) return VCS_OK;
@@ -1064,6 +1065,33 @@ int vcs_gop_upload(vcs_ctx *c, int first, int n, const uint8_t *frames) {
     return VCS_OK;
 }
 
+// The tail kernel reads the GOP's frames 0.6 ms after the search kernel did, and finds none
+// of them in the 256 MB Infinity Cache: the search's scattered 48-byte row pieces do not
+// leave the lines there, a stream of full-line reads does.  k_l3_prefetch is that stream, run
+// between the two kernels: 0.04 ms of reading buys 0.09 ms of tail (0.42 -> 0.33 ms; HBM then
+// serves the tail's 1.44 GB of plane writes without interleaved reads).  Running it BESIDE the
+// search instead (own stream; own slice per search workgroup on its way out) was measured too:
+// the search, which lives on short dependent loads, stretches by 0.04-0.1 ms.  DESIGN.md 5.
+__global__ __launch_bounds__(256) void k_l3_prefetch(const uint4 *__restrict__ p, size_t n16,
+                                                      uint32_t *__restrict__ sink) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 v = p[i];
+        acc |= v.x & v.y & v.z & v.w;
+    }
+    if (acc == 0xFFFFFFFEu) *sink = acc;  // keeps the loads; 16 bytes of 0xFF..FE in a row do not occur... and would be harmless
+}
+
+constexpr size_t kL3PrefetchMaxBytes = (size_t)208 << 20;  // frames the 256 MB cache holds beside the reference
+
+inline bool l3_prefetch_on() {
+    static const bool v = [] {
+        const char *e = getenv("VCS_L3_PREFETCH");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 int vcs_gop_encode(vcs_ctx *c, int first, int n) {
     const bool split = c && c->split_cus > 0 && c->g.N > 0 && n > 0;
     int rc = use(c, /*join=*/!split);
@@ -1101,15 +1129,40 @@ int vcs_gop_encode(vcs_ctx *c, int first, int n) {
         c->tail_n = n;
         return rc;
     }
-    rc = launch_me(c, c->d_ref, curs, c->Fs, n, mv, c->g_ns + first, nullptr);
-    if (rc) return rc;
-    if (c->ev_me_done) {  // the group's collectives start behind the search, beside the tail
-        HIP_TRY(c, hipEventRecord(c->ev_me_done, c->stream));
-        c->me_done_rec = true;
+    // Infinity Cache prefetch (k_l3_prefetch above): for GOP-sized batches (a single frame was
+    // uploaded a moment ago).  A GOP whose frames do not fit beside the reference is encoded in
+    // sub-batches that do (search, prefetch, tail per sub-batch; 8 frames at 4K) -- otherwise what
+    // is read first would be gone again when the tail gets there.
+    size_t chunk = (size_t)n;
+    const bool pf = l3_prefetch_on() && n >= 2 && N > 0;
+    if (pf && (size_t)n * c->Fs > kL3PrefetchMaxBytes) {
+        chunk = kL3PrefetchMaxBytes / c->Fs;
+        if (chunk >= 4) chunk &= ~(size_t)3;          // whole 4-frame groups of the search kernel
+        if (chunk < 2) chunk = (size_t)n;             // frames too large to hold two: one batch, no prefetch
     }
-    if (N == 0)  // no full motion block: the prediction is all zero (motion.py:45-46)
-        return launch_fdct<0>(c, VCS_T_ENC_TAIL, curs, c->Fs, nullptr, nullptr, n, planes, pe);
-    return launch_fdct<1>(c, VCS_T_ENC_TAIL, curs, c->Fs, c->d_ref, mv, n, planes, pe);
+    const bool pf_on = pf && chunk * c->Fs <= kL3PrefetchMaxBytes;
+    for (size_t f0 = 0; f0 < (size_t)n; f0 += chunk) {
+        const int m = (int)std::min(chunk, (size_t)n - f0);
+        const uint8_t *cc = curs + f0 * c->Fs;
+        int16_t *mvc = mv + f0 * N * 2;
+        c->t_no_count = f0 > 0;                      // timing: one "launch" per call, whatever the batching
+        rc = launch_me(c, c->d_ref, cc, c->Fs, m, mvc, c->g_ns + first + f0, nullptr);
+        if (!rc && f0 + m == (size_t)n && c->ev_me_done) {  // the group's collectives start behind the search, beside the tail
+            if (hipEventRecord(c->ev_me_done, c->stream) != hipSuccess) rc = fail(c, VCS_E_HIP, "hipEventRecord failed");
+            c->me_done_rec = true;
+        }
+        if (!rc && pf_on && m >= 2)
+            hipLaunchKernelGGL(k_l3_prefetch, dim3(2048), dim3(256), 0, c->stream, (const uint4 *)cc,
+                               (size_t)m * c->Fs / 16, (uint32_t *)c->d_clk + 30);
+        void *pl = (char *)planes + f0 * planes_bytes(c);
+        if (!rc)
+            rc = N == 0  // no full motion block: the prediction is all zero (motion.py:45-46)
+                     ? launch_fdct<0>(c, VCS_T_ENC_TAIL, cc, c->Fs, nullptr, nullptr, m, pl, pe)
+                     : launch_fdct<1>(c, VCS_T_ENC_TAIL, cc, c->Fs, c->d_ref, mvc, m, pl, pe);
+        c->t_no_count = false;
+        if (rc) return rc;
+    }
+    return VCS_OK;
 }
 
 int vcs_gop_decode(vcs_ctx *c, int first, int n) {
