@@ -37,6 +37,7 @@ constexpr int kMe16gMirror = 15;   // ring slots 0..14 repeated at 80..94
 constexpr int kMe16gRowB = 18 * 16;
 constexpr int kMe16gWinBytes = (kMe16gRing + kMe16gMirror) * kMe16gRowB;
 constexpr int kMe16gWaveBytes = 16 * 4 * kMe16CurPitch + 4 * 40;  // s_cur + s_part (36 used)
+constexpr int kMe16gDumpBytes = 64 * 16;                          // per wave: where the prefetch's bytes go
 
 // LDS-only workgroup barrier: every wave's DS operations are complete and visible, the
 // global loads in flight (register prefetch of the next block) are NOT waited for.
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WPS, WPS
 void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
              Geom g, int n_frames, int seg_len, const uint32_t *__restrict__ sums,
              int16_t *__restrict__ mv, uint32_t *__restrict__ n_static,
-             unsigned long long *__restrict__ cost_out, unsigned long long *__restrict__ clk_out) {
+             unsigned long long *__restrict__ cost_out, unsigned long long *__restrict__ clk_out,
+             int pf_on) {
     using Cfg = Me16gCfg<W>;
     // shader-clock cycles this workgroup lives (s_memtime): the longest-lived workgroup's
     // count over the launch's duration is the clock the chip held under this load
@@ -189,12 +191,22 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 #endif
     constexpr int ROWB = kMe16gRowB, RING = kMe16gRing;
     constexpr int BS = 16, WIN = 32, STEP = 5, NG = kMe16Groups;
-    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe16gWinBytes + W * kMe16gWaveBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe16gWinBytes + W * kMe16gWaveBytes + W * kMe16gDumpBytes];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the frame's addresses stay uniform
     uint8_t *const s_win = s_lds;
     uint32_t *const s_cur = (uint32_t *)(s_lds + kMe16gWinBytes + wave * kMe16gWaveBytes);
     uint32_t *const s_part = s_cur + 16 * kMe16CurPitch;
+    // Infinity Cache prefetch for the tail kernel (vcs_api.hip: k_l3_prefetch explains why): every
+    // workgroup streams its own slice of the launch's frames, one 16-byte LDS-direct load per lane
+    // and block -- no register, no consumer; the bytes land in a dump area nobody reads.  The
+    // search's own accesses (48-byte row pieces) do not leave lines in that cache.
+    uint8_t *const s_dump = s_lds + kMe16gWinBytes + W * kMe16gWaveBytes + wave * kMe16gDumpBytes;
+    const uint32_t pf_total = pf_on ? (uint32_t)(((size_t)n_frames * cur_stride) >> 4) : 0u;   // uint4 units
+    const uint32_t pf_per = (pf_total + gridDim.x - 1) / gridDim.x;
+    uint32_t pf_pos = min(blockIdx.x * pf_per, pf_total);
+    const uint32_t pf_end = min(pf_pos + pf_per, pf_total);
+    const __amdgpu_buffer_rsrc_t r_pf = buf_rsrc(curs, pf_total << 4);
 
     // ---- work units: (frame group, column segment, block column); XCD-contiguous chunks so
     // that the workgroups of one XCD sweep neighbouring columns of the same segment together.
@@ -312,6 +324,11 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
         const bool roll = !last && Bn != B;  // uniform over the workgroup
         Me16gRegs<W> Bq;
         issue(byn, Bn, Bq);
+        if (pf_pos < pf_end) {   // uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_pf, (__attribute__((address_space(3))) void *)s_dump, 16,
+                                                     (int)((pf_pos + (uint32_t)tid) << 4), 0, 0, 0);
+            pf_pos += 64 * W;
+        }
         VCS_TICK(0);  // issue
 
         // everybody has finished block by-1 (its window rows may be replaced) and the rows
@@ -523,7 +540,7 @@ template <int W, int WPS>
 inline int launch_me_group_t(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                              const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
                              uint32_t *ns, unsigned long long *cost, unsigned long long *clk,
-                             hipEvent_t ev_start, hipEvent_t ev_stop) {
+                             bool *prefetch, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int seg = me16g_seg_len(g.nby);
     const long long units = (long long)((n + W - 1) / W) * ((g.nby + seg - 1) / seg) * g.nbx;
     // resident workgroups: WPS waves per SIMD = 4 * WPS waves per CU = 4 * WPS / W workgroups
@@ -536,19 +553,31 @@ inline int launch_me_group_t(const Geom &g, hipStream_t stream, int cus, const u
     grid = (grid + 7) / 8 * 8;
     const long long cap = (units + 7) / 8 * 8;
     dim3 gd((unsigned)(grid > cap ? cap : grid)), block(64 * W);
+    // The in-kernel prefetch covers the frames only if every workgroup walks enough blocks for
+    // its slice (one 16-byte load per lane and block); otherwise the caller runs k_l3_prefetch.
+    int pf_on = 0;
+    if (prefetch && *prefetch) {
+        const long long total16 = (long long)n * (long long)stride / 16;
+        const long long per = (total16 + gd.x - 1) / gd.x, need_blocks = (per + 64 * W - 1) / (64 * W);
+        const int last_seg = g.nby - (g.nby - 1) / seg * seg;            // the shortest segment
+        const long long have_blocks = units / gd.x * (long long)(last_seg < seg ? last_seg : seg);
+        pf_on = total16 * 16 < 0xFFFFFFFFll && have_blocks >= need_blocks;
+        *prefetch = pf_on != 0;
+    }
     hipExtLaunchKernelGGL((k_me16g<W, WPS>), gd, block, 0, stream, ev_start, ev_stop, 0, ref, curs,
-                          stride, g, n, seg, (const uint32_t *)sums, mv, ns, cost, clk);
+                          stride, g, n, seg, (const uint32_t *)sums, mv, ns, cost, clk, pf_on);
     return 0;
 }
 
 inline int launch_me_group(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                            const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
                            uint32_t *ns, unsigned long long *cost, unsigned long long *clk = nullptr,
-                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+                           bool *prefetch = nullptr, hipEvent_t ev_start = nullptr,
+                           hipEvent_t ev_stop = nullptr) {
     if ((long long)g.N * n > 0x7FFFFFFF) return -1;
 #define VCS_ME16G(Wv, Pv)                                                                         \
     return launch_me_group_t<Wv, Pv>(g, stream, cus, ref, curs, stride, n, sums, mv, ns, cost,    \
-                                     clk, ev_start, ev_stop)
+                                     clk, prefetch, ev_start, ev_stop)
     const int w = me16g_group(), p = me16g_wps();
     if (w == 1) { if (p == 2) VCS_ME16G(1, 2); if (p == 4) VCS_ME16G(1, 4); VCS_ME16G(1, 3); }
     if (w == 2) { if (p == 2) VCS_ME16G(2, 2); if (p == 4) VCS_ME16G(2, 4); VCS_ME16G(2, 3); }

@@ -105,6 +105,7 @@ struct vcs_ctx {
     std::vector<EvPair> pool;
     double acc_ms[VCS_T_COUNT] = {0, 0, 0, 0};
     uint64_t launches[VCS_T_COUNT] = {0, 0, 0, 0};
+    bool pf_in_search = false;  // in: the caller wants the frames prefetched; out: the search kernel does it
     bool t_no_count = false;   // a later sub-batch of one vcs_gop_encode call: time it, do not count it
     std::string err;
 };
@@ -264,7 +265,7 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     if (fast16) {
         rc = roll ? (me16g_worthwhile(c->g, c->cus, n)
                          ? launch_me_group(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv,
-                                           ns, cost, c->timing ? c->d_clk : nullptr, ev.a, ev.b)
+                                           ns, cost, c->timing ? c->d_clk : nullptr, &c->pf_in_search, ev.a, ev.b)
                          : launch_me_roll(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv,
                                           ns, cost, ev.a, ev.b))
                   : launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost,
@@ -1082,6 +1083,14 @@ __global__ __launch_bounds__(256) void k_l3_prefetch(const uint4 *__restrict__ p
     if (acc == 0xFFFFFFFEu) *sink = acc;  // keeps the loads; 16 bytes of 0xFF..FE in a row do not occur... and would be harmless
 }
 
+inline bool l3_prefetch_in_search() {   // VCS_L3_PREFETCH=2: always the separate pass
+    static const bool v = [] {
+        const char *e = getenv("VCS_L3_PREFETCH");
+        return !(e && e[0] == '2');
+    }();
+    return v;
+}
+
 constexpr size_t kL3PrefetchMaxBytes = (size_t)208 << 20;  // frames the 256 MB cache holds beside the reference
 
 inline bool l3_prefetch_on() {
@@ -1146,12 +1155,15 @@ int vcs_gop_encode(vcs_ctx *c, int first, int n) {
         const uint8_t *cc = curs + f0 * c->Fs;
         int16_t *mvc = mv + f0 * N * 2;
         c->t_no_count = f0 > 0;                      // timing: one "launch" per call, whatever the batching
+        c->pf_in_search = pf_on && m >= 2 && l3_prefetch_in_search();
         rc = launch_me(c, c->d_ref, cc, c->Fs, m, mvc, c->g_ns + first + f0, nullptr);
+        const bool pf_done = c->pf_in_search;
+        c->pf_in_search = false;
         if (!rc && f0 + m == (size_t)n && c->ev_me_done) {  // the group's collectives start behind the search, beside the tail
             if (hipEventRecord(c->ev_me_done, c->stream) != hipSuccess) rc = fail(c, VCS_E_HIP, "hipEventRecord failed");
             c->me_done_rec = true;
         }
-        if (!rc && pf_on && m >= 2)
+        if (!rc && pf_on && m >= 2 && !pf_done)
             hipLaunchKernelGGL(k_l3_prefetch, dim3(2048), dim3(256), 0, c->stream, (const uint4 *)cc,
                                (size_t)m * c->Fs / 16, (uint32_t *)c->d_clk + 30);
         void *pl = (char *)planes + f0 * planes_bytes(c);
