@@ -22,7 +22,10 @@ enum { kMe8Search = 0, kMe8Sums = 1 };  // k_me8<MODE>: motion search / the refe
 
 constexpr int kMe8Rows = 32;     // 2 * win
 constexpr int kMe8Groups = 11;   // ceil(32 px / 3)
-constexpr int kMe8Slots = 24;    // 16-byte slots per LDS window row
+#ifndef VCS_ME8_SLOTS
+#define VCS_ME8_SLOTS 24
+#endif
+constexpr int kMe8Slots = VCS_ME8_SLOTS;    // 16-byte slots per LDS window row (11 hold pixels; the rest spreads rows over banks)
 constexpr int kMe8RowB = kMe8Slots * 16;
 constexpr int kMe8StgN = (kMe8Rows * kMe8Groups + 63) / 64;  // 6 loads per lane
 constexpr int kMe8SumStride = 64;

@@ -37,7 +37,7 @@ constexpr int kMe16gMirror = 15;   // ring slots 0..14 repeated at 80..94
 constexpr int kMe16gRowB = 18 * 16;
 constexpr int kMe16gWinBytes = (kMe16gRing + kMe16gMirror) * kMe16gRowB;
 constexpr int kMe16gWaveBytes = 16 * 4 * kMe16CurPitch + 4 * 40;  // s_cur + s_part (36 used)
-constexpr int kMe16gDumpBytes = 64 * 16;                          // per wave: where the prefetch's bytes go
+constexpr int kMe16gDumpBytes = 64 * 16;                          // where the prefetch's bytes go (all waves)
 
 // LDS-only workgroup barrier: every wave's DS operations are complete and visible, the
 // global loads in flight (register prefetch of the next block) are NOT waited for.
@@ -191,7 +191,7 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
 #endif
     constexpr int ROWB = kMe16gRowB, RING = kMe16gRing;
     constexpr int BS = 16, WIN = 32, STEP = 5, NG = kMe16Groups;
-    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe16gWinBytes + W * kMe16gWaveBytes + W * kMe16gDumpBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe16gWinBytes + W * kMe16gWaveBytes + kMe16gDumpBytes];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the frame's addresses stay uniform
     uint8_t *const s_win = s_lds;
@@ -201,7 +201,7 @@ void k_me16g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, 
     // workgroup streams its own slice of the launch's frames, one 16-byte LDS-direct load per lane
     // and block -- no register, no consumer; the bytes land in a dump area nobody reads.  The
     // search's own accesses (48-byte row pieces) do not leave lines in that cache.
-    uint8_t *const s_dump = s_lds + kMe16gWinBytes + W * kMe16gWaveBytes + wave * kMe16gDumpBytes;
+    uint8_t *const s_dump = s_lds + kMe16gWinBytes + W * kMe16gWaveBytes;   // one area for all waves: nobody reads it
     const uint32_t pf_total = pf_on ? (uint32_t)(((size_t)n_frames * cur_stride) >> 4) : 0u;   // uint4 units
     const uint32_t pf_per = (pf_total + gridDim.x - 1) / gridDim.x;
     uint32_t pf_pos = min(blockIdx.x * pf_per, pf_total);

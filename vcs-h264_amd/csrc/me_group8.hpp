@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(WPS, WPS
 void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, size_t cur_stride,
             Geom g, int n_frames, int seg_len, const uint32_t *__restrict__ sums,
             int16_t *__restrict__ mv, uint32_t *__restrict__ n_static,
-            unsigned long long *__restrict__ cost_out) {
+            unsigned long long *__restrict__ cost_out, int pf_on) {
     using Cfg = Me8gCfg<W>;
 #ifdef VCS_EXP_PHASES
     unsigned long long ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
@@ -107,11 +107,18 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
 #endif
     constexpr int ROWB = kMe8RowB, RING = kMe8gRing, NG = kMe8Groups, RB = kMe8gRB, LIVE = kMe8gLive;
     constexpr int BS = 8, WIN = 16, STEP = 3;
-    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe8gWinBytes + W * kMe8gWaveBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kMe8gWinBytes + W * kMe8gWaveBytes + kMe16gDumpBytes];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t *const s_win = s_lds;
     uint32_t *const s_cur = (uint32_t *)(s_lds + kMe8gWinBytes + wave * kMe8gWaveBytes);
+    // Infinity Cache prefetch of the launch's frames for the tail kernel (see k_me16g)
+    uint8_t *const s_dump = s_lds + kMe8gWinBytes + W * kMe8gWaveBytes;   // one area for all waves: nobody reads it
+    const uint32_t pf_total = pf_on ? (uint32_t)(((size_t)n_frames * cur_stride) >> 4) : 0u;
+    const uint32_t pf_per = (pf_total + gridDim.x - 1) / gridDim.x;
+    uint32_t pf_pos = min(blockIdx.x * pf_per, pf_total);
+    const uint32_t pf_end = min(pf_pos + pf_per, pf_total);
+    const __amdgpu_buffer_rsrc_t r_pf = buf_rsrc(curs, pf_total << 4);
 
     const int nseg = (g.nby + seg_len - 1) / seg_len;
     const int ngroups = (n_frames + W - 1) / W;
@@ -217,6 +224,11 @@ void k_me8g(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ curs, s
         const bool park = meet && by + RB < by1;            // somebody comes after the next meeting
         Me8gRegs<W> Bq;
         issue(last ? by : by + 1, Bq);
+        if (meet && pf_pos < pf_end) {   // uniform; once per meeting is plenty at 8x8
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_pf, (__attribute__((address_space(3))) void *)s_dump, 16,
+                                                     (int)((pf_pos + (uint32_t)tid) << 4), 0, 0, 0);
+            pf_pos += 64 * W;
+        }
 
         VCS_TICK(0);
         // Meeting: everybody has finished the blocks before this one (their oldest rows may be
@@ -385,8 +397,8 @@ inline bool me8g_worthwhile(const Geom &g, int cus, int n) {
 template <int W, int WPS>
 inline int launch_me_group8_t(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                               const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
-                              uint32_t *ns, unsigned long long *cost, hipEvent_t ev_start,
-                              hipEvent_t ev_stop) {
+                              uint32_t *ns, unsigned long long *cost, bool *prefetch,
+                              hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int seg = me8g_seg_len(g.nby);
     const long long units = (long long)((n + W - 1) / W) * ((g.nby + seg - 1) / seg) * g.nbx;
     static const int per_cu_env = [] {
@@ -398,19 +410,28 @@ inline int launch_me_group8_t(const Geom &g, hipStream_t stream, int cus, const 
     grid = (grid + 7) / 8 * 8;
     const long long cap = (units + 7) / 8 * 8;
     dim3 gd((unsigned)(grid > cap ? cap : grid)), block(64 * W);
+    int pf_on = 0;   // as in launch_me_group_t: only if every workgroup meets often enough for its slice
+    if (prefetch && *prefetch) {
+        const long long total16 = (long long)n * (long long)stride / 16;
+        const long long per = (total16 + gd.x - 1) / gd.x, need = (per + 64 * W - 1) / (64 * W);
+        const int last_seg = g.nby - (g.nby - 1) / seg * seg;
+        const long long have = units / gd.x * (long long)((last_seg < seg ? last_seg : seg) / kMe8gRB);
+        pf_on = total16 * 16 < 0xFFFFFFFFll && have >= need;
+        *prefetch = pf_on != 0;
+    }
     hipExtLaunchKernelGGL((k_me8g<W, WPS>), gd, block, 0, stream, ev_start, ev_stop, 0, ref, curs,
-                          stride, g, n, seg, (const uint32_t *)sums, mv, ns, cost);
+                          stride, g, n, seg, (const uint32_t *)sums, mv, ns, cost, pf_on);
     return 0;
 }
 
 inline int launch_me_group8(const Geom &g, hipStream_t stream, int cus, const uint8_t *ref,
                             const uint8_t *curs, size_t stride, int n, uint32_t *sums, int16_t *mv,
-                            uint32_t *ns, unsigned long long *cost, hipEvent_t ev_start = nullptr,
-                            hipEvent_t ev_stop = nullptr) {
+                            uint32_t *ns, unsigned long long *cost, bool *prefetch = nullptr,
+                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     if ((long long)g.N * n > 0x7FFFFFFF) return -1;
 #define VCS_ME8G(Wv, Pv)                                                                           \
     return launch_me_group8_t<Wv, Pv>(g, stream, cus, ref, curs, stride, n, sums, mv, ns, cost,    \
-                                      ev_start, ev_stop)
+                                      prefetch, ev_start, ev_stop)
     const int w = me8g_group(), p = me8g_wps();
     if (w == 1) { if (p <= 3) VCS_ME8G(1, 3); if (p >= 6) VCS_ME8G(1, 6); VCS_ME8G(1, 4); }
     if (w == 2) { if (p <= 3) VCS_ME8G(2, 3); if (p >= 6) VCS_ME8G(2, 6); VCS_ME8G(2, 4); }

@@ -258,6 +258,8 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     }
     const bool fast16 = c->me_fast_ok && !force_generic;
     const bool group8 = c->me_fast8_ok && !force_generic && me8g_worthwhile(c->g, c->cus, n);
+    bool pf = c->pf_in_search;   // prefetch request: only the shared-window kernels can serve it
+    c->pf_in_search = false;
     EvPair ev;
     int rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/fast16 || group8);  // the search kernel alone
     if (rc) return rc;
@@ -265,15 +267,17 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     if (fast16) {
         rc = roll ? (me16g_worthwhile(c->g, c->cus, n)
                          ? launch_me_group(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv,
-                                           ns, cost, c->timing ? c->d_clk : nullptr, &c->pf_in_search, ev.a, ev.b)
+                                           ns, cost, c->timing ? c->d_clk : nullptr, &pf, ev.a, ev.b)
                          : launch_me_roll(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv,
                                           ns, cost, ev.a, ev.b))
                   : launch_me_fast(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost,
                                    ev.a, ev.b);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
+        c->pf_in_search = pf && roll && me16g_worthwhile(c->g, c->cus, n);
     } else if (group8) {
-        rc = launch_me_group8(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost, ev.a, ev.b);
+        rc = launch_me_group8(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost, &pf, ev.a, ev.b);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
+        c->pf_in_search = pf;
     } else if (c->me_fast8_ok && !force_generic) {
         rc = launch_me_fast8(c->g, c->stream, c->cus, ref, curs, stride, n, c->d_sums, mv, ns, cost);
         if (rc) return fail(c, VCS_E_HIP, "fast ME launch failed");
