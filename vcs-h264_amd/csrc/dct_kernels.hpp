@@ -92,15 +92,26 @@ __device__ __forceinline__ double div_markstein(double a, double b, double y) {
 // loads are unconditional (a conditional load makes hipcc wait for it on the
 // spot, which serialises the eight rows of a strip), and the result is
 // selected afterwards.  Needs g.N > 0.
-__device__ __forceinline__ uint32_t pred_px(const uint8_t *__restrict__ ref,
-                                            const int16_t *__restrict__ mv, const Geom &g,
-                                            int y, int x) {
+// pred_mv: the vector (dx | dy << 16) of the block that covers (y, x) clamped into the covered
+// area; pred_px_m: the pixel it points at.  Motion blocks are multiples of 8 in every
+// BASELINE configuration, so the 8 rows of a k_fdct strip column share one block: the kernel
+// then fetches the vector once instead of 8 times (tail 0.335 -> 0.303 ms).
+__device__ __forceinline__ uint32_t pred_mv(const int16_t *__restrict__ mv, const Geom &g, int y, int x) {
     const int yc = min(y, g.nby * g.bs - 1), xc = min(x, g.nbx * g.bs - 1);
     const int blk = (yc / g.bs) * g.nbx + (xc / g.bs);
-    const uint32_t m = load_px((const uint8_t *)(mv + 2 * blk));  // dx | dy << 16
+    return load_px((const uint8_t *)(mv + 2 * blk));
+}
+__device__ __forceinline__ uint32_t pred_px_m(const uint8_t *__restrict__ ref, const Geom &g, int y,
+                                              int x, uint32_t m) {
+    const int yc = min(y, g.nby * g.bs - 1), xc = min(x, g.nbx * g.bs - 1);
     const int dx = (int16_t)(m & 0xFFFFu), dy = (int16_t)(m >> 16);
     const uint32_t v = load_px(ref + (size_t)(yc + dy) * g.pitch + (size_t)(3 * (xc + dx)));
     return (yc == y && xc == x) ? v : 0u;
+}
+__device__ __forceinline__ uint32_t pred_px(const uint8_t *__restrict__ ref,
+                                            const int16_t *__restrict__ mv, const Geom &g,
+                                            int y, int x) {
+    return pred_px_m(ref, g, y, x, pred_mv(mv, g, y, x));
 }
 
 
@@ -196,11 +207,21 @@ __global__ __launch_bounds__(64) void k_fdct(
     // ---- fetch column x of the 8-row strip (all loads unconditional) ---------
     const int xl = min(x, g.W - 1);
     uint32_t px[8], pp[8];
+    if (MODE == 1 && (g.bs & 7) == 0) {   // uniform: one vector for the column's 8 rows
+        const uint32_t m = pred_mv(mv, g, ty * 8, xl);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int y = ty * 8 + k;
-        px[k] = load_px(img + (size_t)y * g.pitch + (size_t)(3 * xl));
-        pp[k] = MODE == 1 ? pred_px(ref, mv, g, y, xl) : 0u;
+        for (int k = 0; k < 8; k++) {
+            const int y = ty * 8 + k;
+            px[k] = load_px(img + (size_t)y * g.pitch + (size_t)(3 * xl));
+            pp[k] = pred_px_m(ref, g, y, xl, m);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int y = ty * 8 + k;
+            px[k] = load_px(img + (size_t)y * g.pitch + (size_t)(3 * xl));
+            pp[k] = MODE == 1 ? pred_px(ref, mv, g, y, xl) : 0u;
+        }
     }
     wave_lds_fence();
     double X[3][8];
@@ -305,7 +326,7 @@ __global__ __launch_bounds__(64) void k_idct(
     const int y = ty * 8 + j, xo = min(gx * 64 + t * 8, g.W - 8);
     uint32_t pp[8];
 #pragma unroll
-    for (int jj = 0; jj < 8; jj++) pp[jj] = MODE == 1 ? pred_px(ref, mv, g, y, xo + jj) : 0u;
+    for (int jj = 0; jj < 8; jj++) pp[jj] = MODE == 1 ? pred_px(ref, mv, g, y, xo + jj) : 0u;   // (one vector load for the 8 pixels was measured: 6 % slower, the chain gets longer)
     wave_lds_fence();
 
     int ycc[3][8];  // row i = j of the tile, 8 pixels, after stage 2
