@@ -22,6 +22,14 @@ namespace vcs {
 
 constexpr int kTilePad = 72;  // doubles per tile in the LDS transpose buffer
 constexpr int kOutPad = 9;    // elements per output row in the LDS store buffer (8 + 1 pad)
+#ifndef VCS_FDCT_WAVES
+#define VCS_FDCT_WAVES 4
+#endif
+constexpr int kFdctWaves = VCS_FDCT_WAVES;  // strips (waves) per k_fdct workgroup
+#ifndef VCS_IDCT_WAVES
+#define VCS_IDCT_WAVES 1
+#endif
+constexpr int kIdctWaves = VCS_IDCT_WAVES;   // k_idct is bound by its 1.44 GB of plane reads: 1, 2, 4 waves measure the same
 
 // coefficient store / load for the three coefficient modes (vcs_hip.h)
 template <int CM> struct CoeffT;
@@ -124,10 +132,11 @@ __device__ __forceinline__ uint32_t pred_px(const uint8_t *__restrict__ ref,
 //   map 2: XCD x owns the same band of strips in every frame.
 // The grid is 1-D with tail_grid() workgroups; false = nothing to do.
 struct TailUnit { int f, ty, gx; };
-__device__ __forceinline__ bool tail_unit(const Geom &g, int n_frames, int map, TailUnit &u) {
+__device__ __forceinline__ bool tail_unit(const Geom &g, int n_frames, int map, TailUnit &u,
+                                          long long L = -1) {
     const int groups_x = (g.W + 63) >> 6, per_frame = groups_x * (g.H >> 3);
     const long long total = (long long)per_frame * n_frames;
-    const long long L = blockIdx.x;
+    if (L < 0) L = blockIdx.x;
     long long id;
     if (map == 1) {
         const long long chunk = (total + 7) >> 3;
@@ -176,7 +185,7 @@ template <class T> struct Vec2 { typedef T type __attribute__((ext_vector_type(2
 // DQ: D[64] (unused here: kDct8), Q[3][64], then 1/Q[3][64] (correctly rounded), float64, in HBM.
 // --------------------------------------------------------------------------
 template <int MODE, int CM, bool FASTDIV>
-__global__ __launch_bounds__(64) void k_fdct(
+__global__ __launch_bounds__(64 * kFdctWaves) void k_fdct(
     const uint8_t *__restrict__ imgs, size_t img_stride, const uint8_t *__restrict__ ref,
     const int16_t *__restrict__ mvs, Geom g, const double *__restrict__ DQ,
     typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride, int n_frames, int map) {
@@ -186,24 +195,26 @@ __global__ __launch_bounds__(64) void k_fdct(
     // operations of one wave execute in order).
     static_assert(64 * kOutPad * sizeof(typename CoeffT<CM>::type) <= 8 * kTilePad * sizeof(double),
                   "s_o must fit in s_t");
-    __shared__ double s_t[8 * kTilePad];
-    typename CoeffT<CM>::type *const s_o = (typename CoeffT<CM>::type *)s_t;
+    // A workgroup is kFdctWaves waves, one strip each; they have nothing in common but the
+    // quantiser table in LDS, staged once per workgroup instead of once per strip.
+    __shared__ double s_tw[kFdctWaves][8 * kTilePad];
     __shared__ double s_q[(FASTDIV ? 48 : 24) * kOutPad];  // Q[3][8][8] (then 1/Q), rows padded to 9
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *const s_t = s_tw[wave];
+    typename CoeffT<CM>::type *const s_o = (typename CoeffT<CM>::type *)s_t;
     const int t = lane >> 3, j = lane & 7;
+    const double *__restrict__ Qg = DQ + 64;
+    for (int e = threadIdx.x; e < (FASTDIV ? 384 : 192); e += 64 * kFdctWaves)
+        s_q[(e >> 3) * kOutPad + (e & 7)] = Qg[e];
     TailUnit tu;
-    if (!tail_unit(g, n_frames, map, tu)) return;
+    const bool has_unit = tail_unit(g, n_frames, map, tu, (long long)blockIdx.x * kFdctWaves + wave);
+    if (kFdctWaves > 1) __syncthreads();   // s_q complete (every wave arrives exactly once)
+    if (!has_unit) return;
     const int ty = tu.ty, gx = tu.gx, f = tu.f;
     const int x = gx * 64 + lane;  // stage-1 pixel column of this lane
     const uint8_t *__restrict__ img = imgs + (size_t)f * img_stride;
     const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
-    const double *__restrict__ Q = DQ + 64;
-
-    // ---- Q (and 1/Q) into LDS: later reads must not share vmcnt with the stores --
-    for (int e = lane; e < (FASTDIV ? 384 : 192); e += 64) {
-        const int row = e >> 3;
-        s_q[row * kOutPad + (e & 7)] = Q[e];
-    }
+    // (Q and 1/Q are in LDS: their reads must not share vmcnt with the stores)
     // ---- fetch column x of the 8-row strip (all loads unconditional) ---------
     const int xl = min(x, g.W - 1);
     uint32_t px[8], pp[8];
@@ -295,27 +306,28 @@ __global__ __launch_bounds__(64) void k_fdct(
 // motion-compensated prediction with uint8 wrap (decoder.py:52-69).
 // --------------------------------------------------------------------------
 template <int MODE, int CM>
-__global__ __launch_bounds__(64) void k_idct(
+__global__ __launch_bounds__(64 * kIdctWaves) void k_idct(
     const typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride,
     const uint8_t *__restrict__ ref, const int16_t *__restrict__ mvs, Geom g,
     const double *__restrict__ DQ, uint8_t *__restrict__ outs, size_t out_stride, int n_frames,
     int map) {
-    __shared__ double s_t[8 * kTilePad];
+    __shared__ double s_tw[kIdctWaves][8 * kTilePad];   // one strip per wave, as in k_fdct
     __shared__ double s_q[24 * kOutPad];  // Q[3][8][8], rows padded to 9
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *const s_t = s_tw[wave];
     const int t = lane >> 3, j = lane & 7;
+    for (int e = threadIdx.x; e < 192; e += 64 * kIdctWaves) s_q[(e >> 3) * kOutPad + (e & 7)] = DQ[64 + e];
     TailUnit tu;
-    if (!tail_unit(g, n_frames, map, tu)) return;
+    const bool has_unit = tail_unit(g, n_frames, map, tu, (long long)blockIdx.x * kIdctWaves + wave);
+    if (kIdctWaves > 1) __syncthreads();
+    if (!has_unit) return;
     const int ty = tu.ty, gx = tu.gx, f = tu.f;
     const int x = gx * 64 + lane;
     const int xl = min(x, g.W - 1);  // lanes past the frame edge: clamped loads, no stores
     const size_t plane = (size_t)g.H * g.W;
     const typename CoeffT<CM>::type *__restrict__ in = planes + (size_t)f * planes_stride;
     const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
-    const double *__restrict__ Q = DQ + 64;
-
     // ---- every global load up front, branch-free ----------------------------------
-    for (int e = lane; e < 192; e += 64) s_q[(e >> 3) * kOutPad + (e & 7)] = Q[e];
     double X[3][8];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++)

@@ -326,7 +326,7 @@ int launch_fdct(vcs_ctx *c, int tslot, const uint8_t *imgs, size_t stride, const
     if (n == 0) return VCS_OK;
     const Geom &g = c->g;
     const int map = tail_map();
-    dim3 grid(tail_grid(g, n, map)), block(64);
+    dim3 grid((tail_grid(g, n, map) + kFdctWaves - 1) / kFdctWaves), block(64 * kFdctWaves);
     EvPair ev;
     int rc = t_begin(c, tslot, &ev, /*attach=*/true);
     if (rc) return rc;
@@ -354,7 +354,7 @@ int launch_idct(vcs_ctx *c, int tslot, const void *planes, size_t pstride_elems,
     if (n == 0) return VCS_OK;
     const Geom &g = c->g;
     const int map = tail_map();
-    dim3 grid(tail_grid(g, n, map)), block(64);
+    dim3 grid((tail_grid(g, n, map) + kIdctWaves - 1) / kIdctWaves), block(64 * kIdctWaves);
     EvPair ev;
     int rc = t_begin(c, tslot, &ev, /*attach=*/true);
     if (rc) return rc;
