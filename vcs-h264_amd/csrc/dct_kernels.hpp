@@ -78,6 +78,13 @@ __device__ __forceinline__ uint32_t load_px(const uint8_t *p) {
     __builtin_memcpy(&v, p, 4);
     return v;
 }
+// the same from a wave-uniform base and an unsigned 32-bit byte offset: the base stays in
+// scalar registers and the load needs no 64-bit vector address arithmetic
+__device__ __forceinline__ uint32_t load_px_o(const uint8_t *__restrict__ base, uint32_t off) {
+    uint32_t v;
+    __builtin_memcpy(&v, base + off, 4);
+    return v;
+}
 // a / b, correctly rounded, from y = RN(1 / b) in three fused operations
 // (Markstein): q = RN(a*y); r = RN(a - q*b) (exact); result = RN(q + r*y).
 // Valid when nothing over/underflows, b > 0 and b's significand is not all ones; the
@@ -107,13 +114,15 @@ __device__ __forceinline__ double div_markstein(double a, double b, double y) {
 __device__ __forceinline__ uint32_t pred_mv(const int16_t *__restrict__ mv, const Geom &g, int y, int x) {
     const int yc = min(y, g.nby * g.bs - 1), xc = min(x, g.nbx * g.bs - 1);
     const int blk = (yc / g.bs) * g.nbx + (xc / g.bs);
-    return load_px((const uint8_t *)(mv + 2 * blk));
+    return load_px_o((const uint8_t *)mv, 4u * (uint32_t)blk);
 }
+// (the vectors the search kernels produce, and the ones the host lets through, keep the
+// predicted block inside the frame: the offset below is never negative)
 __device__ __forceinline__ uint32_t pred_px_m(const uint8_t *__restrict__ ref, const Geom &g, int y,
                                               int x, uint32_t m) {
     const int yc = min(y, g.nby * g.bs - 1), xc = min(x, g.nbx * g.bs - 1);
     const int dx = (int16_t)(m & 0xFFFFu), dy = (int16_t)(m >> 16);
-    const uint32_t v = load_px(ref + (size_t)(yc + dy) * g.pitch + (size_t)(3 * (xc + dx)));
+    const uint32_t v = load_px_o(ref, (uint32_t)((yc + dy) * g.pitch + 3 * (xc + dx)));
     return (yc == y && xc == x) ? v : 0u;
 }
 __device__ __forceinline__ uint32_t pred_px(const uint8_t *__restrict__ ref,
@@ -223,14 +232,14 @@ __global__ __launch_bounds__(64 * kFdctWaves) void k_fdct(
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int y = ty * 8 + k;
-            px[k] = load_px(img + (size_t)y * g.pitch + (size_t)(3 * xl));
+            px[k] = load_px_o(img + (size_t)y * g.pitch, 3u * (uint32_t)xl);
             pp[k] = pred_px_m(ref, g, y, xl, m);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int y = ty * 8 + k;
-            px[k] = load_px(img + (size_t)y * g.pitch + (size_t)(3 * xl));
+            px[k] = load_px_o(img + (size_t)y * g.pitch, 3u * (uint32_t)xl);
             pp[k] = MODE == 1 ? pred_px(ref, mv, g, y, xl) : 0u;
         }
     }
@@ -291,7 +300,8 @@ __global__ __launch_bounds__(64 * kFdctWaves) void k_fdct(
             if (xc < g.W) {
                 const OutT v0 = s_o[(tt * 8 + row) * kOutPad + jj];
                 const OutT v1 = s_o[(tt * 8 + row) * kOutPad + jj + 1];
-                OutT *o = out + ch * plane + (size_t)(ty * 8 + row) * g.W + xc;
+                // uniform plane base + 32-bit element offset (a 4K plane is 8.3 M elements)
+                OutT *o = (out + ch * plane) + (uint32_t)((ty * 8 + row) * g.W + xc);
                 typename Vec2<OutT>::type pr;
                 pr.x = v0, pr.y = v1;
                 VCS_NT_STORE(pr, (typename Vec2<OutT>::type *)o);
