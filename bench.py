@@ -535,7 +535,21 @@ def main():
             dt = group.max_over_ranks(dt)
         return dt, t_enq, per, cyc
 
-    dt, t_enq, per, cyc = timed(sets, args.steps, max(args.warmup, sets if sets > 1 else 0))
+    # Two passes of W warm-up + K timed steps.  The first starts on an idle GPU: its 20-odd
+    # milliseconds fall into the clock governor's ramp (measured: 2.06 GHz and 253 k
+    # macroblocks/ms against 2.25 GHz and 265 k once the GPU has been busy for 0.1 s).  Between
+    # the passes the same step runs untimed for ~0.25 s, so that the second pass -- the
+    # headline -- is what a stream of GOPs sees; the first is reported beside it.
+    warm = max(args.warmup, sets if sets > 1 else 0)
+    dt0, _, per0, cyc0 = timed(sets, args.steps, warm)
+    first_pass = {"value": round(n_total * N * args.steps / dt0 / 1e3, 2), "unit": "macroblocks/ms",
+                  "ms_per_step": round(dt0 / args.steps * 1e3, 4),
+                  "kernel_ms_per_step": {"me": round(per0[0][0][vcs_hip.T_ME] / args.steps, 4),
+                                         "enc_tail": round(per0[0][0][vcs_hip.T_ENC_TAIL] / args.steps, 4)},
+                  "note": "the same %d + %d steps started on an idle GPU, inside the clock ramp" % (warm, args.steps)}
+    cond_ms = float(os.environ.get("VCS_BENCH_CONDITION_MS", "250"))
+    cond_steps = min(5000, int(cond_ms / max(1e-3, dt0 / args.steps * 1e3))) if cond_ms > 0 else 0
+    dt, t_enq, per, cyc = timed(sets, args.steps, warm + cond_steps)
     ms, launches = per[0]
 
     # what was just timed: vectors of the last GOP (all shards'), static counts
@@ -617,6 +631,9 @@ def main():
                                        "uploaded the I frame itself and kept its vectors, ranks met through "
                                        "files" % rccl_failed if rccl_failed else
                                        "in-library RCCL broadcast (I frame) + all-gather (vectors) per GOP: " + transport)},
+            "clock_conditioning": {"untimed_steps_before_the_warmup": cond_steps,
+                                   "why": "the timed steps run at the sustained clock; VCS_BENCH_CONDITION_MS=0 turns it off"},
+            "idle_start_first_pass": first_pass,
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "kernel_ms_per_step": {"me": round(ms[vcs_hip.T_ME] / args.steps, 4),
                                    "enc_tail": round(ms[vcs_hip.T_ENC_TAIL] / args.steps, 4)},
@@ -663,7 +680,7 @@ def main():
     if not args.no_extras and sets > 1:
         # the loop over ONE resident GOP: its 29 input frames (180 MB) are read again every
         # step and stay in the 256 MB Infinity Cache -- every rank takes part (collectives)
-        dt1, _, per1, _ = timed(1, args.steps, 2)
+        dt1, _, per1, _ = timed(1, args.steps, 2 + cond_steps)   # same clock conditioning as the headline
         if rank == 0:
             m1, l1 = per1[0]
             out["resident_one_gop"] = {
