@@ -60,7 +60,10 @@ def main(path):
                "frame (SURVEY 8d) while neighbouring strips share it in L2.  k_me16g's WRITE_SIZE "
                "is mostly its scratch backing store (12 spilled registers of the 128-VGPR build: 48 B x 64 "
                "lanes x 4,096 waves = 12.6 MB, written once per wave in the unit prologue), not results: "
-               "the vectors are 0.93 MB per launch.  The strips of k_fdct are dealt in raster order."
+               "the vectors are 0.93 MB per launch; its FETCH_SIZE includes the 180 MB of frames it streams "
+               "once more, as full lines, for the tail kernel (the in-kernel Infinity Cache prefetch), which "
+               "is why its traffic is now above its algorithmic bytes.  The strips of k_fdct are dealt in "
+               "raster order; its reads of those frames are served by the Infinity Cache (FETCH_SIZE counts them)."
                % sampled,
         "source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)) + "/.."),
         "kernels": kernels,
