@@ -12,6 +12,7 @@ drop-in classes / the C ABI), every result compared with the CPU oracle:
 Plus the regressions behind ADVICE.md (round 1): parameters pushed by one drop-in
 class survive the other classes' pushes; an I frame edited in place is seen.
 """
+import os
 import numpy as np
 import pytest
 
@@ -331,3 +332,44 @@ def test_config2_1080p_pair_reference_and_dense_search(vh, oracle):
         _, oplanes, _ = oracle.encode_p(cur, ref, bs, step=1)
         assert np.array_equal(planes.view(np.int64), oplanes.view(np.int64))
         assert np.array_equal(c.decode_p(mv2, planes), oracle.decode_p(omv, oplanes, ref, bs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bs", [16, 8])
+def test_gop_in_cache_sized_sub_batches(bs):
+    """vcs_gop_encode splits a GOP whose frames do not fit the Infinity Cache into sub-batches
+    (search + prefetch + tail each).  Forced here with a tiny cache budget (the library reads
+    VCS_L3_PREFETCH_MAX_KB once, hence the child process): 11 frames in batches of 4, 4, 3 must
+    give what frame-by-frame calls and the oracle give, for the shared-window search kernels
+    (VCS_ME16_ROLL=2) with their in-kernel prefetch and for the separate prefetch pass."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = r'''
+import os, sys
+sys.path[:0] = [%r, %r]
+import numpy as np
+import vcs_hip
+from oracle import oracle
+from synth import synth_gop
+bs = %d
+H, W, n = 144, 176, 11
+ref, frames = synth_gop(H, W, n, seed=21)
+with vcs_hip.Context(H, W, bs, 8) as c:
+    c.set_ref(ref)
+    c.gop_reserve(n)
+    c.gop_upload(0, frames)
+    c.gop_encode(0, n)
+    mv, ns = c.gop_get_mv(0, n)
+    for k in range(n):
+        omv, oplanes, _ = oracle.encode_p(frames[k], ref, bs)
+        assert np.array_equal(mv[k], omv), k
+        assert np.array_equal(c.gop_get_planes(k).view(np.int64), oplanes.view(np.int64)), k
+print("ok")
+''' % (os.path.dirname(here), os.path.join(os.path.dirname(here), "vcs-h264_amd"), bs)
+    frame_kb = (144 * 176 * 3 + 64 + 255) // 256 * 256 / 1024.0
+    for mode in ("1", "2"):
+        env = dict(os.environ, VCS_L3_PREFETCH=mode, VCS_ME16_ROLL="2",
+                   VCS_L3_PREFETCH_MAX_KB=str(int(4 * frame_kb) + 1))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (mode, r.stdout[-500:], r.stderr[-2000:])

@@ -1095,7 +1095,15 @@ inline bool l3_prefetch_in_search() {   // VCS_L3_PREFETCH=2: always the separat
     return v;
 }
 
-constexpr size_t kL3PrefetchMaxBytes = (size_t)208 << 20;  // frames the 256 MB cache holds beside the reference
+// frames the 256 MB cache holds beside the reference (VCS_L3_PREFETCH_MAX_KB: tests force sub-batches)
+inline size_t l3_prefetch_max_bytes() {
+    static const size_t v = [] {
+        const char *e = getenv("VCS_L3_PREFETCH_MAX_KB");
+        const long long kb = e ? atoll(e) : 0;
+        return kb > 0 ? (size_t)kb << 10 : (size_t)208 << 20;
+    }();
+    return v;
+}
 
 inline bool l3_prefetch_on() {
     static const bool v = [] {
@@ -1148,12 +1156,12 @@ int vcs_gop_encode(vcs_ctx *c, int first, int n) {
     // is read first would be gone again when the tail gets there.
     size_t chunk = (size_t)n;
     const bool pf = l3_prefetch_on() && n >= 2 && N > 0;
-    if (pf && (size_t)n * c->Fs > kL3PrefetchMaxBytes) {
-        chunk = kL3PrefetchMaxBytes / c->Fs;
+    if (pf && (size_t)n * c->Fs > l3_prefetch_max_bytes()) {
+        chunk = l3_prefetch_max_bytes() / c->Fs;
         if (chunk >= 4) chunk &= ~(size_t)3;          // whole 4-frame groups of the search kernel
         if (chunk < 2) chunk = (size_t)n;             // frames too large to hold two: one batch, no prefetch
     }
-    const bool pf_on = pf && chunk * c->Fs <= kL3PrefetchMaxBytes;
+    const bool pf_on = pf && chunk * c->Fs <= l3_prefetch_max_bytes();
     for (size_t f0 = 0; f0 < (size_t)n; f0 += chunk) {
         const int m = (int)std::min(chunk, (size_t)n - f0);
         const uint8_t *cc = curs + f0 * c->Fs;
