@@ -690,7 +690,13 @@ def test_forced_kernel_variants_subprocess():
                        ({"VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "0", "VCS_ME8_GROUP": "0"}, sel),
                        ({"VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "2", "VCS_ME16_WPS": "3"}, sel),
                        ({"VCS_ME16_ROLL": "0"}, sel),
-                       ({"VCS_ME_GENERIC": "1"}, sel), ({"VCS_FAST_DIV": "0"}, dct)):
+                       ({"VCS_ME_GENERIC": "1"}, sel), ({"VCS_FAST_DIV": "0"}, dct),
+                       # the tail kernels' other strip -> workgroup mappings (4 strips per workgroup)
+                       ({"VCS_TAIL_MAP": "1"}, dct + " or gop_1080p_vs_oracle"),
+                       ({"VCS_TAIL_MAP": "2"}, dct + " or gop_1080p_vs_oracle"),
+                       # Infinity Cache prefetch as a separate pass / off (default: inside the search kernel)
+                       ({"VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "2"}, "gop_1080p_vs_oracle or gop_matches_single"),
+                       ({"VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "0"}, "gop_1080p_vs_oracle or gop_matches_single")):
         env = dict(os.environ, **env_add)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
                             "-m", "gpu", "-x", "-q", "-k", k, "-p", "no:cacheprovider"],
