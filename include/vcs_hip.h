@@ -56,7 +56,8 @@ enum {                  /* indices into vcs_timing()                        */
     VCS_T_ENC_TAIL = 1, /* MC + residual + colour + DCT + quantise kernel   */
     VCS_T_DEC = 2,      /* dequantise + IDCT + colour + MC-add kernel       */
     VCS_T_AUX = 3,      /* stand-alone mc / residual / compress kernels     */
-    VCS_T_COUNT = 4
+    VCS_T_ME_PREP = 4,  /* bit-plane search: current blocks -> planes + static test (k_bits_cur) */
+    VCS_T_COUNT = 5
 };
 
 typedef struct vcs_ctx vcs_ctx;

@@ -1,0 +1,487 @@
+// me_bits.hpp -- k_me16b: the 16x16 / +-32 / stride-5 motion search on BIT PLANES.
+//
+// motion.py:146 scores a candidate with sum((ref - cur) mod 256) over 768 bytes, which is
+// sum(r) - sum(c) + 256 * #{r < c}.  sum(r) comes from the per-reference table (k_me16_sums),
+// sum(c) is one number per block, so the work is counting byte pairs with r < c: 76,800
+// pairs per block.  k_me16g counts them four at a time (v_lerp_u8 -> v_and -> v_bcnt, 3
+// vector instructions per 4 pairs).  Here the bytes are stored as bit planes, 32 pairs per
+// dword and plane, and [r < c] is the borrow of c - r ... the carry chain of an 8-bit
+// compare run from plane 0 to plane 7:   b' = majority(~r_k, c_k, b).
+// gfx950 has v_bitop3_b32 (any 3-input boolean function in one instruction), so a chain is
+// 8 instructions + one v_bcnt per 32 pairs: 9 / 32 instead of 24 / 32.
+//
+// Operand routing (lane = candidate, as in k_me16):
+//   * r, the window: every (row pair, candidate column) position of the reference is
+//     pre-cut into a 96-byte chunk -- two 48-byte rows = 3 dwords x 8 planes -- by k_bits_ref,
+//     once per reference frame ("rtab").  A lane loads its candidate's chunk (6 x 16 bytes,
+//     contiguous across the 10 candidate columns) and keeps it in 24 registers ...
+//   * ... while it loops over the FRAMES of the GOP: all P frames search the same I frame
+//     (encoder.py:51-52), so a wave owns one block position and up to NF frames; the window
+//     operand is loaded once per NF frames;
+//   * c, the current block: the same for every lane of the wave (one block, one frame, one
+//     row pair) -> scalar registers.  k_bits_cur writes every block of every P frame as 8 row
+//     pairs x 24 plane dwords ("cpl"), the search reads them with s_load; v_bitop3_b32 takes
+//     the plane from an SGPR.  k_bits_cur also does the static test (motion.py:109-116) and
+//     sum(c), and its full-line reads of the frames leave them in the Infinity Cache for the
+//     tail kernel (what k_me16g's in-kernel prefetch did).
+// No LDS, no barrier, no cross-lane traffic until the arg-min.  A static block costs nothing
+// in the search (a scalar branch over its frame), divergence-free.
+// Candidates 64..99 of an interior block run as a second pass with 36 of 64 lanes busy.
+// Results are identical to k_me16 / k_me16g / k_me_generic (tests/test_gpu_parity.py).
+#pragma once
+#include <hip/hip_ext.h>
+
+#include "me_fast.hpp"
+
+namespace vcs {
+
+constexpr int kBitsT = 24;                    // dwords per row-pair chunk: t = 8 * d + k (d: dword of the 96-byte string, k: plane)
+constexpr int kBitsBlk = 8 * kBitsT;          // dwords per 16x16x3 block (8 row pairs)
+constexpr int kBitsM = 10;                    // candidate columns per block column
+constexpr int kBitsWA = 6 * kBitsM * 4;       // dwords per (window row, block column): [q = t / 4][m][4]
+
+// 8 dwords = 32 bytes -> 8 plane dwords, in place: x[k] bit (8 t + j) = bit k of byte t of the
+// old x[j].  Four 8x8 bit-matrix transposes at once (one per byte column), three butterfly
+// stages.  The order of the 32 bits inside a plane dword is arbitrary but the same for the
+// reference chunks and the current blocks, which is all the comparison needs.
+__device__ __forceinline__ void bits_transpose8(uint32_t (&x)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t t = ((x[j] >> 4) ^ x[j + 4]) & 0x0F0F0F0Fu;
+        x[j + 4] ^= t;
+        x[j] ^= t << 4;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int j = 4 * h; j < 4 * h + 2; j++) {
+            const uint32_t t = ((x[j] >> 2) ^ x[j + 2]) & 0x33333333u;
+            x[j + 2] ^= t;
+            x[j] ^= t << 2;
+        }
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const uint32_t t = ((x[j] >> 1) ^ x[j + 1]) & 0x55555555u;
+        x[j + 1] ^= t;
+        x[j] ^= t << 1;
+    }
+}
+
+// ---- reference chunks ---------------------------------------------------------------------
+// rtab[((w * nbx + a) * 6 + q) * 40 + m * 4 + e] = plane dword t = 4 q + e of the 96-byte string
+// (row w, bytes 3 j .. 3 j + 47) ++ (row w + 1, same bytes), j = max(16 a - 32, 0) + 5 m: the
+// m-th candidate column of block column a (motion.py:125-140).  Every w: a candidate's rows
+// start at i_min + 5 ci, of either parity.  One thread per (w, a, m).
+__global__ __launch_bounds__(256) void k_bits_ref(const uint8_t *__restrict__ ref, uint32_t ref_bytes, Geom g,
+                                                  uint32_t *__restrict__ rtab) {
+    const uint32_t total = (uint32_t)g.H * (uint32_t)g.nbx * kBitsM;
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= total) return;
+    const uint32_t m = idx % kBitsM, wa = idx / kBitsM;
+    const uint32_t a = wa % (uint32_t)g.nbx, w = wa / (uint32_t)g.nbx;
+    const int j = max(16 * (int)a - 32, 0) + 5 * (int)m;
+    const __amdgpu_buffer_rsrc_t r_ref = buf_rsrc(ref, ref_bytes);   // reads past the slack rows return 0
+    const uint32_t off = w * (uint32_t)g.pitch + 3u * (uint32_t)j;
+    uint32_t s[24];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {   // unaligned dwords (tools/buf_test.hip)
+        s[i] = buf_ld32(r_ref, off + 4u * i, 0);
+        s[12 + i] = buf_ld32(r_ref, off + (uint32_t)g.pitch + 4u * i, 0);
+    }
+    uint4 *dst = (uint4 *)(rtab + (size_t)wa * kBitsWA + m * 4);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = s[8 * d + i];
+        bits_transpose8(x);
+        dst[(2 * d) * kBitsM] = make_uint4(x[0], x[1], x[2], x[3]);
+        dst[(2 * d + 1) * kBitsM] = make_uint4(x[4], x[5], x[6], x[7]);
+    }
+}
+
+// ---- current blocks -----------------------------------------------------------------------
+// cpl[((f * N + blk) * 8 + p) * 24 + 8 d + k]: row pair p of block blk of frame f as plane
+// dwords; binfo[f * N + blk] = {sum(max(ref - cur, 0)) over the co-located block, sum(cur)}
+// (motion.py:109-116, the static test, and the -sum(c) of the cost); n_static[f] += static
+// blocks.  A workgroup = 32 consecutive blocks of one frame: their 16 x 48-byte rows are
+// fetched as 16-byte pieces (with the co-located reference piece, for the static test) and
+// parked in LDS; then 768 (block, row pair, d) tasks, three per thread, transpose 32 bytes
+// each.  The frames are read whole-line by whole-line here, which also leaves them in the
+// Infinity Cache for the tail kernel.
+constexpr int kBitsCurBlocks = 32;
+__global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ curs, size_t cur_stride,
+                                                  const uint8_t *__restrict__ ref, Geom g,
+                                                  uint32_t *__restrict__ cpl, uint2 *__restrict__ binfo,
+                                                  uint32_t *__restrict__ n_static) {
+    __shared__ uint4 s_blk[kBitsCurBlocks * 48];    // [block][row][3 pieces]
+    __shared__ uint32_t s_acc[kBitsCurBlocks][3];   // sum|r - c|, sum r, sum c per block
+    __shared__ uint32_t s_ns;
+    const int tid = threadIdx.x;
+    const int f = blockIdx.y;
+    const int blk0 = blockIdx.x * kBitsCurBlocks;
+    if (tid < kBitsCurBlocks * 3) (&s_acc[0][0])[tid] = 0;
+    if (tid == 0) s_ns = 0;
+    __syncthreads();
+    const uint32_t fbytes = (uint32_t)(g.H * g.pitch);
+    const __amdgpu_buffer_rsrc_t r_cur = buf_rsrc(curs + (size_t)f * cur_stride, fbytes);
+    const __amdgpu_buffer_rsrc_t r_ref = buf_rsrc(ref, fbytes);
+    uint4 vc[6], vr[6];
+#pragma unroll
+    for (int it = 0; it < 6; it++) {   // 32 blocks x 16 rows x 3 pieces = 1,536 = 6 x 256
+        const int e = tid + 256 * it, bi = e / 48, r = e - bi * 48, row = r / 3, seg = r - row * 3;
+        const int blk = min(blk0 + bi, g.N - 1);
+        const int byi = blk / g.nbx, bxi = blk - byi * g.nbx;
+        const uint32_t o = (uint32_t)((byi * 16 + row) * g.pitch + 48 * bxi + 16 * seg);
+        vc[it] = buf_ld128(r_cur, o, 0);
+        vr[it] = buf_ld128(r_ref, o, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+        const int e = tid + 256 * it, bi = e / 48;
+        s_blk[e] = vc[it];
+        const uint32_t c4[4] = {vc[it].x, vc[it].y, vc[it].z, vc[it].w};
+        const uint32_t r4[4] = {vr[it].x, vr[it].y, vr[it].z, vr[it].w};
+        uint32_t sad = 0, sr = 0, sc = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            sad = __builtin_amdgcn_sad_u8(r4[i], c4[i], sad);
+            sr = __builtin_amdgcn_sad_u8(r4[i], 0u, sr);
+            sc = __builtin_amdgcn_sad_u8(c4[i], 0u, sc);
+        }
+        atomicAdd(&s_acc[bi][0], sad);
+        atomicAdd(&s_acc[bi][1], sr);
+        atomicAdd(&s_acc[bi][2], sc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 3; it++) {   // 32 blocks x 8 row pairs x 3 string thirds = 768 = 3 x 256
+        const int e = tid + 256 * it, bi = e / 24, r = e - bi * 24, p = r / 3, d = r - p * 3;
+        const int blk = blk0 + bi;
+        // the 96-byte string of row pair p = pieces 0..5 of rows 2p, 2p + 1; third d = pieces 2d, 2d + 1
+        const uint4 lo = s_blk[bi * 48 + 6 * p + 2 * d], hi = s_blk[bi * 48 + 6 * p + 2 * d + 1];
+        uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        bits_transpose8(x);
+        if (blk < g.N) {
+            uint4 *dst = (uint4 *)(cpl + ((size_t)f * g.N + blk) * kBitsBlk + p * kBitsT + 8 * d);
+            dst[0] = make_uint4(x[0], x[1], x[2], x[3]);
+            dst[1] = make_uint4(x[4], x[5], x[6], x[7]);
+        }
+    }
+    if (tid < kBitsCurBlocks) {
+        const int blk = blk0 + tid;
+        if (blk < g.N) {
+            // sum(max(r - c, 0)) = (sum|r - c| + sum r - sum c) / 2
+            const uint32_t sdiff = (s_acc[tid][0] + s_acc[tid][1] - s_acc[tid][2]) >> 1;
+            binfo[(size_t)f * g.N + blk] = make_uint2(sdiff, s_acc[tid][2]);
+            if (!g.never_static && sdiff <= g.thresh) atomicAdd(&s_ns, 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && s_ns) atomicAdd(&n_static[f], s_ns);
+}
+
+// ---- the search ---------------------------------------------------------------------------
+// One comparison step of the borrow chain on 32 pairs: r < c so far (b), planes r, c.
+__device__ __forceinline__ uint32_t bits_lt_step(uint32_t r, uint32_t c, uint32_t b) {
+    const uint32_t x = r ^ c;          // selects to ONE v_bitop3_b32 with the line below
+    return (x & c) | (~x & b);         // r != c: c decides (c = 1, r = 0: r < c); r == c: keep
+}
+// #{r < c} over the 96 byte pairs of one chunk: 3 dwords x 8 planes, t = 8 d + k
+__device__ __forceinline__ uint32_t bits_count_lt(const uint32_t (&r)[kBitsT], const uint32_t (&c)[kBitsT]) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        uint32_t b = c[8 * d] & ~r[8 * d];   // plane 0: r < c iff r = 0, c = 1
+#pragma unroll
+        for (int k = 1; k < 8; k++) b = bits_lt_step(r[8 * d + k], c[8 * d + k], b);
+        n += (uint32_t)__builtin_popcount(b);
+    }
+    return n;
+}
+__device__ __forceinline__ void bits_ld_chunk(uint32_t (&r)[kBitsT], const uint32_t *__restrict__ rp) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const uint4 v = *(const uint4 *)(rp + q * (kBitsM * 4));
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+}
+
+// frames [f0, f0 + nf) of group `grp` when n frames are dealt to `ngroups` waves as evenly as possible
+__device__ __forceinline__ void bits_group(int n, int ngroups, int grp, int &f0, int &nf) {
+    const int q = n / ngroups, r = n - q * ngroups;
+    f0 = grp * q + min(grp, r);
+    nf = q + (grp < r ? 1 : 0);
+}
+
+// LDS of one wave: the planes of its NF current blocks, [row pair][frame][96 bytes] (filled by
+// LDS-direct loads, one per row pair), and the second pass's counts, [frame][40]
+template <int NF>
+struct BitsLds {
+    static constexpr int kPlanes = 8 * NF * 96, kPart = NF * 40 * 4, kWave = kPlanes + kPart;
+};
+
+template <int NF>
+__global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab, const uint32_t *__restrict__ cpl,
+                                               const uint2 *__restrict__ binfo, const uint32_t *__restrict__ sums,
+                                               Geom g, int n_frames, int ngroups, int16_t *__restrict__ mv,
+                                               unsigned long long *__restrict__ cost_out,
+                                               unsigned long long *__restrict__ clk_out) {
+    constexpr int BS = 16, WIN = 32, STEP = 5;
+    using L = BitsLds<NF>;
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[4 * L::kWave];
+    const unsigned long long clk0 = clk_out ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *const s_c = s_lds + wave * L::kWave;
+    uint32_t *const s_part = (uint32_t *)(s_c + L::kPlanes);
+    // units = (block position, frame group), column-major over the block positions (down a block
+    // column the chunk rows of vertically adjacent blocks overlap: they meet in the XCD's L2), dealt
+    // to the 8 XCDs in contiguous ranges; a workgroup = 4 consecutive units (the 4 frame groups of
+    // one block position when ngroups = 4: they read the same chunks through one L1)
+    const int total = g.N * ngroups;
+    const int chunk = ((total + 7) / 8 + 3) & ~3;
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3;
+    const int ul = wg * 4 + wave;
+    const int u = xcd * chunk + ul;
+    if (ul < chunk && u < total) {
+        const int pos = u / ngroups, grp = u - pos * ngroups;
+        const int bxi = pos / g.nby, byi = pos - bxi * g.nby;
+        const int blk = byi * g.nbx + bxi;
+        int f0, nf;
+        bits_group(n_frames, ngroups, grp, f0, nf);
+        const int x = bxi * BS, y = byi * BS;
+        const int i_min = max(y - WIN, 0), i_max = min(y + WIN, g.H);
+        const int j_min = max(x - WIN, 0), j_max = min(x + WIN, g.W);
+        const int ri = i_max - BS - i_min, rj = j_max - BS - j_min;
+        const int nci = ri >= 1 ? (ri - 1) / STEP + 1 : 0;
+        const int ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
+        const int ncand = nci * ncj;
+        const uint32_t inv_ncj = ncj ? 65536u / (uint32_t)ncj + 1u : 0u;   // cand / ncj for cand < 128, ncj <= 10
+
+        // per frame: static? (scalar)
+        uint32_t sdiff[NF], sumc[NF];
+        uint32_t skip = 0;   // bit f: nothing to search for frame f0 + f
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            sdiff[f] = 0;
+            sumc[f] = 0;
+            if (f < nf) {
+                const uint2 bi = binfo[(size_t)(f0 + f) * g.N + blk];
+                sdiff[f] = bi.x;
+                sumc[f] = bi.y;
+                if (!g.never_static && bi.x <= g.thresh) skip |= 1u << f;
+            } else {
+                skip |= 1u << f;
+            }
+        }
+
+        uint32_t best[NF];
+#pragma unroll
+        for (int f = 0; f < NF; f++) best[f] = 0xFFFFFFFFu;
+
+        const size_t wstride = (size_t)g.nbx * kBitsWA;   // dwords per window row of rtab
+        const uint32_t *__restrict__ cblk = cpl + ((size_t)f0 * g.N + blk) * kBitsBlk;
+        const size_t cfs = (size_t)g.N * kBitsBlk;         // dwords per frame of cpl
+
+        if (skip != (1u << NF) - 1u && ncand > 0) {
+            // The planes of the wave's NF current blocks arrive by LDS-direct loads, one instruction
+            // per row pair (lane = (frame, 16-byte piece)), two rounds ahead of their use.  They are
+            // read twice: by the first pass through s_load from L2 -- a scalar load that misses L2
+            // takes ~2,000 cycles and a wave has one in flight; the LDS-direct load is what brings the
+            // line into L2 in time (measured: 0.49 ms without, 0.22 ms with every plane load hitting)
+            // -- and by the second pass from LDS.
+            const __amdgpu_buffer_rsrc_t r_c = buf_rsrc(cblk, 0xFFFFFFFFu);
+            const int pf_f = min(lane / 6, nf - 1), pf_q = lane - (lane / 6) * 6;
+            const uint32_t pf_off = (uint32_t)pf_f * (uint32_t)(cfs * 4) + 16u * (uint32_t)pf_q;
+            auto prefetch = [&](int p) {
+                if (lane < NF * 6)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        r_c, (__attribute__((address_space(3))) void *)(s_c + p * (NF * 96)), 16,
+                        (int)(pf_off + (uint32_t)p * 96u), 0, 0, 0);
+            };
+            prefetch(0);
+            prefetch(1);
+
+            // ---- first pass: candidates 0..63, lane = candidate, planes of the block in SGPRs ------
+            {
+                const bool act = lane < ncand;
+                const int cc = act ? lane : 0;
+                const int ci = (int)(((uint32_t)cc * inv_ncj) >> 16), cj = cc - ci * ncj;
+                const uint32_t sr = sums[(size_t)blk * kMe16SumStride + cc];
+                const uint32_t *__restrict__ rp =
+                    rtab + (size_t)(i_min + STEP * ci) * wstride + (size_t)bxi * kBitsWA + cj * 4;
+                uint32_t acc[NF];
+#pragma unroll
+                for (int f = 0; f < NF; f++) acc[f] = 0;
+                // one round = one row pair: the chunk of the round is in `cur`; the next round's chunk
+                // and the planes two rounds ahead are requested behind the first frame (the wait that
+                // frame's first use of `cur` draws covers everything issued a round ago, nothing newer)
+                auto round = [&](const uint32_t (&cur)[kBitsT], uint32_t (&nxt)[kBitsT], int p, bool has_next) {
+#pragma unroll
+                    for (int f = 0; f < NF; f++) {
+                        if (!((skip >> f) & 1u)) {   // scalar branch
+#ifdef VCS_EXP_BITS_SAMEC   // experiment builds only (results are wrong): every plane load hits the scalar cache
+                            const uint32_t *__restrict__ c = cblk + (f & 1) * kBitsT;
+#else
+                            const uint32_t *__restrict__ c = cblk + (size_t)f * cfs + p * kBitsT;
+#endif
+                            uint32_t cs[kBitsT];
+#pragma unroll
+                            for (int t = 0; t < kBitsT; t++) cs[t] = c[t];
+                            acc[f] += bits_count_lt(cur, cs);
+                        }
+                        if (f == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (has_next) {
+                                rp += 2 * wstride;
+                                bits_ld_chunk(nxt, rp);
+                            }
+                            if (p + 2 < 8) prefetch(p + 2);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                };
+                uint32_t ra[kBitsT], rb[kBitsT];
+                bits_ld_chunk(ra, rp);
+#pragma unroll 1
+                for (int p = 0; p < 8; p += 2) {
+                    round(ra, rb, p, true);
+                    round(rb, ra, p + 1, p + 2 < 8);
+                }
+#pragma unroll
+                for (int f = 0; f < NF; f++)
+                    if (act) best[f] = ((sr + 256u * acc[f]) << 7) | (uint32_t)lane;
+            }
+
+            // ---- second pass: candidates 64.., lane = (candidate, row pair), planes from LDS ------
+            if (ncand > 64) {
+                const int n2 = ncand - 64, ntask = 8 * n2;
+                const uint32_t inv_n2 = 65536u / (uint32_t)n2 + 1u;   // t / n2 for t < 288, n2 <= 36
+                if (lane < 40) {
+#pragma unroll
+                    for (int f = 0; f < NF; f++) s_part[f * 40 + lane] = 0;
+                }
+                // the LDS-direct loads have landed (this wave's own: its vmcnt is what orders them)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wave_lds_fence();
+                for (int j = 0; j * 64 < ntask; j++) {
+                    const int t = lane + 64 * j;
+                    const bool act = t < ntask;
+                    const int tc = act ? t : 0;
+                    const int p = (int)(((uint32_t)tc * inv_n2) >> 16), ck = tc - p * n2;
+                    const int cand = 64 + ck;
+                    const int ci = (int)(((uint32_t)cand * inv_ncj) >> 16), cj = cand - ci * ncj;
+                    uint32_t r[kBitsT];
+                    bits_ld_chunk(r, rtab + (size_t)(i_min + STEP * ci + 2 * p) * wstride + (size_t)bxi * kBitsWA + cj * 4);
+                    const uint4 *cq = (const uint4 *)(s_c + p * (NF * 96));
+#pragma unroll
+                    for (int f = 0; f < NF; f++) {
+                        if (!((skip >> f) & 1u)) {   // scalar branch
+                            uint32_t cs[kBitsT];
+#pragma unroll
+                            for (int q = 0; q < 6; q++) {
+                                const uint4 v = cq[f * 6 + q];
+                                cs[4 * q] = v.x; cs[4 * q + 1] = v.y; cs[4 * q + 2] = v.z; cs[4 * q + 3] = v.w;
+                            }
+                            const uint32_t cnt = bits_count_lt(r, cs);
+                            if (act) atomicAdd(&s_part[f * 40 + ck], cnt);
+                        }
+                    }
+                }
+                wave_lds_fence();
+                if (lane < n2) {
+                    const uint32_t sr2 = sums[(size_t)blk * kMe16SumStride + 64 + lane];
+#pragma unroll
+                    for (int f = 0; f < NF; f++)
+                        best[f] = min(best[f], ((sr2 + 256u * s_part[f * 40 + lane]) << 7) | (uint32_t)(64 + lane));
+                }
+                wave_lds_fence();   // the next unit would rewrite s_part (one unit per wave today)
+            }
+        }
+
+        // ---- arg-min per frame (motion.py:149: strict <, raster order = lowest index on ties) -----
+        uint32_t my_mv = 0, my_clo = 0, my_chi = 0;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            if (f < nf) {
+                uint32_t mvw = 0u;
+                unsigned long long cw = sdiff[f];      // static block: [0, 0], cost = the difference
+                const bool is_static = !g.never_static && sdiff[f] <= g.thresh;
+                if (!is_static) {
+                    const uint32_t key = wave_min_u32(best[f]);
+                    int bx = 0, byy = 0;
+                    cw = 9999999999ull;                // motion.py:120: no candidate
+                    if (key != 0xFFFFFFFFu) {
+                        const int cb = (int)(key & 127u);
+                        const int cbi = (int)(((uint32_t)cb * inv_ncj) >> 16);
+                        byy = i_min + cbi * STEP;
+                        bx = j_min + (cb - cbi * ncj) * STEP;
+                        cw = (key >> 7) - sumc[f];
+                    }
+                    mvw = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);  // [dx, dy]
+                }
+                if (lane == f) {
+                    my_mv = mvw;
+                    my_clo = (uint32_t)cw;
+                    my_chi = (uint32_t)(cw >> 32);
+                }
+            }
+        }
+        if (lane < nf) {
+            const size_t o = (size_t)(f0 + lane) * g.N + blk;
+            *(uint32_t *)(mv + 2 * o) = my_mv;
+            if (cost_out) cost_out[o] = (unsigned long long)my_clo | ((unsigned long long)my_chi << 32);
+        }
+    }
+    if (clk_out && threadIdx.x == 0) atomicMax(clk_out, __builtin_amdgcn_s_memtime() - clk0);
+}
+
+// ---- host side ----------------------------------------------------------------------------
+constexpr int kBitsNF = 8;   // frames per wave the search kernel is unrolled for
+
+inline size_t me_bits_rtab_bytes(const Geom &g) { return (size_t)g.H * g.nbx * kBitsWA * 4 + 256; }
+inline size_t me_bits_cpl_bytes(const Geom &g, int n) { return (size_t)n * g.N * kBitsBlk * 4; }
+inline size_t me_bits_binfo_bytes(const Geom &g, int n) { return (size_t)n * g.N * sizeof(uint2); }
+
+// VCS_ME16_BITS: 0 = off (k_me16g / k_me16r / k_me16), 1 = default (batches of >= kBitsMinFrames
+// frames), 2 = every launch (tests run small and ragged frames through it).
+inline int me_bits_mode() {
+    static const int v = [] {
+        const char *e = getenv("VCS_ME16_BITS");
+        const int m = e ? atoi(e) : 1;
+        return m >= 0 && m <= 2 ? m : 1;
+    }();
+    return v;
+}
+constexpr int kBitsMinFrames = 4;
+inline bool me_bits_worthwhile(const Geom &g, int n) {
+    const int m = me_bits_mode();
+    if (m == 0 || !me_fast_supported(g)) return false;
+    if ((long long)g.N * n * kBitsBlk > 0x7FFFFFFFll * 4) return false;
+    return m == 2 || n >= kBitsMinFrames;
+}
+inline int me_bits_groups(int n) { return (n + kBitsNF - 1) / kBitsNF; }
+
+inline void launch_bits_ref(const Geom &g, hipStream_t stream, const uint8_t *ref, size_t ref_bytes, uint32_t *rtab) {
+    const uint32_t total = (uint32_t)g.H * (uint32_t)g.nbx * kBitsM;
+    hipLaunchKernelGGL(k_bits_ref, dim3((total + 255) / 256), dim3(256), 0, stream, ref, (uint32_t)ref_bytes, g, rtab);
+}
+inline void launch_bits_cur(const Geom &g, hipStream_t stream, const uint8_t *curs, size_t stride, const uint8_t *ref,
+                            int n, uint32_t *cpl, uint2 *binfo, uint32_t *ns, hipEvent_t ev_start = nullptr,
+                            hipEvent_t ev_stop = nullptr) {
+    hipExtLaunchKernelGGL(k_bits_cur, dim3((g.N + kBitsCurBlocks - 1) / kBitsCurBlocks, n), dim3(256), 0, stream,
+                          ev_start, ev_stop, 0, curs, stride, ref, g, cpl, binfo, ns);
+}
+inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t *rtab, const uint32_t *cpl,
+                               const uint2 *binfo, const uint32_t *sums, int n, int16_t *mv,
+                               unsigned long long *cost, unsigned long long *clk, hipEvent_t ev_start = nullptr,
+                               hipEvent_t ev_stop = nullptr) {
+    const int ngroups = me_bits_groups(n);
+    const int total = g.N * ngroups;
+    const int chunk = ((total + 7) / 8 + 3) & ~3;
+    hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(8 * (chunk / 4)), dim3(256), 0, stream, ev_start, ev_stop, 0,
+                          rtab, cpl, binfo, sums, g, n, ngroups, mv, cost, clk);
+}
+
+}  // namespace vcs

@@ -21,6 +21,7 @@
 #include "me_roll.hpp"
 #include "me_group.hpp"
 #include "me_group8.hpp"
+#include "me_bits.hpp"
 #include "me_kernels.hpp"
 #include "me_ext.hpp"
 
@@ -63,6 +64,12 @@ struct vcs_ctx {
     uint32_t *d_sums = nullptr;  // k_me16: per-reference sum(r) table
     unsigned long long *d_clk = nullptr;  // k_me16g: longest workgroup lifetime in shader cycles (timing on)
     bool sums_valid = false;
+    // k_me16b (me_bits.hpp): the reference cut into bit-plane chunks (per reference frame), the
+    // current blocks as bit planes + {static-test sum, sum(c)} per block (scratch, per launch)
+    uint32_t *d_rtab = nullptr, *d_cpl = nullptr;
+    uint2 *d_binfo = nullptr;
+    int cpl_frames = 0;      // frames d_cpl / d_binfo hold
+    bool rtab_valid = false;
     int cus = 256;         // compute units of the device
     // single-frame buffers
     uint8_t *d_ref = nullptr, *d_cur = nullptr, *d_a = nullptr, *d_b = nullptr;
@@ -103,8 +110,8 @@ struct vcs_ctx {
     bool timing = false;
     std::vector<EvPair> pending;
     std::vector<EvPair> pool;
-    double acc_ms[VCS_T_COUNT] = {0, 0, 0, 0};
-    uint64_t launches[VCS_T_COUNT] = {0, 0, 0, 0};
+    double acc_ms[VCS_T_COUNT] = {0, 0, 0, 0, 0};
+    uint64_t launches[VCS_T_COUNT] = {0, 0, 0, 0, 0};
     bool pf_in_search = false;  // in: the caller wants the frames prefetched; out: the search kernel does it
     bool t_no_count = false;   // a later sub-batch of one vcs_gop_encode call: time it, do not count it
     std::string err;
@@ -241,12 +248,31 @@ int launch_me_generic_t(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, siz
     return VCS_OK;
 }
 
+// Scratch of the bit-plane search for n frames (grown on demand; allocation synchronises, so it
+// happens on the first launch of a given size only).
+static int ensure_bits(vcs_ctx *c, int n) {
+    if (!c->d_rtab) HIP_TRY(c, hipMalloc(&c->d_rtab, me_bits_rtab_bytes(c->g)));
+    if (n > c->cpl_frames) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_cpl);
+        hipFree(c->d_binfo);
+        c->d_cpl = nullptr;
+        c->d_binfo = nullptr;
+        c->cpl_frames = 0;
+        HIP_TRY(c, hipMalloc(&c->d_cpl, me_bits_cpl_bytes(c->g, n)));
+        HIP_TRY(c, hipMalloc(&c->d_binfo, me_bits_binfo_bytes(c->g, n)));
+        c->cpl_frames = n;
+    }
+    return VCS_OK;
+}
+
 // Motion search for n frames (frame f at curs + f*stride) against `ref`.
 int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride, int n,
               int16_t *mv, uint32_t *ns, unsigned long long *cost, bool force_generic = false) {
     if (c->g.N == 0 || n == 0) return VCS_OK;
+    const bool bits = c->me_fast_ok && !force_generic && me_bits_worthwhile(c->g, n);
     // the per-frame static-block counters start at zero; the rolling kernel's primer does it
-    const bool roll = c->me_fast_ok && !force_generic && me16r_worthwhile(c->g, c->cus, n);
+    const bool roll = !bits && c->me_fast_ok && !force_generic && me16r_worthwhile(c->g, c->cus, n);
     if (!roll) HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
     // per-reference sum(r) table, once per reference frame (all P frames of a GOP share it);
     // not part of VCS_T_ME, which times the search kernel alone
@@ -255,6 +281,25 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         else launch_me_fast8_sums(c->g, c->stream, c->cus, ref, c->d_sums);
         HIP_TRY(c, hipGetLastError());
         c->sums_valid = true;
+        c->rtab_valid = false;
+    }
+    if (bits) {
+        int rc = ensure_bits(c, n);
+        if (rc) return rc;
+        if (!c->rtab_valid) {   // once per reference frame, like the sum table
+            launch_bits_ref(c->g, c->stream, ref, c->Fs + me_fast_ref_slack(c->g), c->d_rtab);
+            HIP_TRY(c, hipGetLastError());
+            c->rtab_valid = true;
+        }
+        EvPair evp, ev;
+        if ((rc = t_begin(c, VCS_T_ME_PREP, &evp, /*attach=*/true))) return rc;
+        launch_bits_cur(c->g, c->stream, curs, stride, ref, n, c->d_cpl, c->d_binfo, ns, evp.a, evp.b);
+        if ((rc = t_end(c, &evp))) return rc;
+        if ((rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/true))) return rc;
+        launch_bits_search(c->g, c->stream, c->d_rtab, c->d_cpl, c->d_binfo, c->d_sums, n, mv, cost,
+                           c->timing ? c->d_clk : nullptr, ev.a, ev.b);
+        // k_bits_cur has read the frames line by line: they are in the Infinity Cache for the tail
+        return t_end(c, &ev);
     }
     const bool fast16 = c->me_fast_ok && !force_generic;
     const bool group8 = c->me_fast8_ok && !force_generic && me8g_worthwhile(c->g, c->cus, n);
@@ -729,6 +774,7 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     hipFree(c->d_coords); hipFree(c->d_cost); hipFree(c->d_ns); hipFree(c->d_planes);
     hipFree(c->d_DQ);
     hipFree(c->d_sums);
+    hipFree(c->d_rtab); hipFree(c->d_cpl); hipFree(c->d_binfo);
     hipFree(c->d_clk);
     hipFree(c->d_intra);
     if (c->xev) hipEventDestroy(c->xev);

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("VCS_HIP_LIB") or os.path.join(_HERE, "lib", "libvcs_h
 VCS_COEFF_F64, VCS_COEFF_F32, VCS_COEFF_I16 = 0, 1, 2
 KEEP_THRESH = -(1 << 63)  # VCS_KEEP_THRESH
 COEFF_DTYPES = {0: np.float64, 1: np.float32, 2: np.int16}
-T_ME, T_ENC_TAIL, T_DEC, T_AUX, T_COUNT = 0, 1, 2, 3, 4
+T_ME, T_ENC_TAIL, T_DEC, T_AUX, T_ME_PREP, T_COUNT = 0, 1, 2, 3, 4, 5
 
 _c_ctx = ctypes.c_void_p
 _u8p = ctypes.POINTER(ctypes.c_uint8)
