@@ -48,6 +48,18 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~5500 measured copy
 # issue cycles per wave-instruction on one SIMD, measured on this chip by tools/ub_valu.hip
 ISSUE_CYCLES = {"v_lerp_u8": 4, "v_and_b32": 2, "v_bcnt_u32_b32": 4, "other": 4}
+# k_me16b is made of v_bitop3_b32 / v_bcnt_u32_b32 (VOP3): 3.6-3.7 issue cycles per wave-instruction
+# with 8 waves per SIMD (tools/ub_bits.hip: 586 G wave-instructions/s chip-wide), priced at 4
+ISSUE_CYCLES_VOP3 = 4
+
+
+def kernel_ms(ms, steps):
+    """Per-step kernel times of one timing() result; me_prep is k_bits_cur (bit-plane search only)."""
+    import vcs_hip
+    out = {"me": round(ms[vcs_hip.T_ME] / steps, 4), "enc_tail": round(ms[vcs_hip.T_ENC_TAIL] / steps, 4)}
+    if ms[vcs_hip.T_ME_PREP] > 0:
+        out["me_prep"] = round(ms[vcs_hip.T_ME_PREP] / steps, 4)
+    return out
 
 
 def cpu_baseline(H, W, bs, ref, frames, budget_s=10.0):
@@ -520,6 +532,7 @@ def main():
             c.timing_enable(not os.environ.get("VCS_BENCH_NO_EVENTS"))
             c.timing_reset()
             c.me_cycles(reset=True)
+            c.me_clock(reset=True)
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -529,6 +542,7 @@ def main():
         dt = time.perf_counter() - t0
         per = [c.timing() for c in ctxs]
         cyc = [c.me_cycles(reset=True) for c in ctxs]
+        state["clock_ghz"] = ctxs[0].me_clock(reset=True)
         for c in ctxs:
             c.timing_enable(False)
         if group is not None:
@@ -544,8 +558,7 @@ def main():
     dt0, _, per0, cyc0 = timed(sets, args.steps, warm)
     first_pass = {"value": round(n_total * N * args.steps / dt0 / 1e3, 2), "unit": "macroblocks/ms",
                   "ms_per_step": round(dt0 / args.steps * 1e3, 4),
-                  "kernel_ms_per_step": {"me": round(per0[0][0][vcs_hip.T_ME] / args.steps, 4),
-                                         "enc_tail": round(per0[0][0][vcs_hip.T_ENC_TAIL] / args.steps, 4)},
+                  "kernel_ms_per_step": kernel_ms(per0[0][0], args.steps),
                   "note": "the same %d + %d steps started on an idle GPU, inside the clock ramp" % (warm, args.steps)}
     cond_ms = float(os.environ.get("VCS_BENCH_CONDITION_MS", "250"))
     cond_steps = min(5000, int(cond_ms / max(1e-3, dt0 / args.steps * 1e3))) if cond_ms > 0 else 0
@@ -577,9 +590,12 @@ def main():
         # algorithmic HBM bytes per macroblock: ME reads cur + ref and writes the
         # vectors; the tail reads cur + ref + vectors, writes 3 f64 planes
         per_mb = {vcs_hip.T_ME: (2 * F + 4 * N) / N, vcs_hip.T_ENC_TAIL: (10 * F + 4 * N) / N}
-        me_name = ("k_me16g" if bs == 16 and n0 >= 4 else "k_me16r/k_me16" if bs == 16
+        bits = launches[vcs_hip.T_ME_PREP] > 0     # the bit-plane search ran (k_bits_cur + k_me16b)
+        me_name = ("k_me16b" if bits else "k_me16g" if bs == 16 and n0 >= 4 else "k_me16r/k_me16" if bs == 16
                    else "k_me8" if bs == 8 else "k_me_generic")
-        names = {vcs_hip.T_ME: me_name, vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
+        names = {vcs_hip.T_ME: "k_bits_cur + k_me16b (the motion-search stage)" if bits else me_name,
+                 vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
+        stage_ms = {vcs_hip.T_ME: ms[vcs_hip.T_ME] + ms[vcs_hip.T_ME_PREP], vcs_hip.T_ENC_TAIL: ms[vcs_hip.T_ENC_TAIL]}
         tj = {}
         traffic = {}
         try:
@@ -591,15 +607,18 @@ def main():
             pass
 
         def roof(slot):
-            avg_ms = ms[slot] / max(1, int(launches[slot]))
+            avg_ms = stage_ms[slot] / max(1, int(launches[slot]))
             alg = per_mb[slot] * n0 * N
             ach = alg / (avg_ms * 1e-3) / 1e9
+            tr = traffic.get(names[slot])
+            if slot == vcs_hip.T_ME and bits:       # the stage's two kernels
+                tr = (traffic.get("k_bits_cur", 0) + traffic.get("k_me16b", 0)) or None
             return {"bound": "hbm", "kernel": names[slot], "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic.get(names[slot]),
+                    "traffic": tr,
                     "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_ms, 4)}
 
-        dom = max(per_mb, key=lambda k: ms[k])
+        dom = max(per_mb, key=lambda k: stage_ms[k])
         other = vcs_hip.T_ENC_TAIL if dom == vcs_hip.T_ME else vcs_hip.T_ME
         transport = vcs_hip.TRANSPORTS.get(group.transport, "?") if group is not None else None
         if args.strong:
@@ -635,8 +654,7 @@ def main():
                                    "why": "the timed steps run at the sustained clock; VCS_BENCH_CONDITION_MS=0 turns it off"},
             "idle_start_first_pass": first_pass,
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
-            "kernel_ms_per_step": {"me": round(ms[vcs_hip.T_ME] / args.steps, 4),
-                                   "enc_tail": round(ms[vcs_hip.T_ENC_TAIL] / args.steps, 4)},
+            "kernel_ms_per_step": kernel_ms(ms, args.steps),
             "roofline": roof(dom),
             "roofline_second_kernel": roof(other),
             # the whole step against HBM: 10F + 4N algorithmic bytes per P frame on GPU 0
@@ -645,6 +663,28 @@ def main():
                              "frac": round((10 * F + 4 * N) * n0 / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "north_star asks for >= 0.40; the search is vector-issue bound (below)"},
         }
+        if me_name == "k_me16b":
+            # The bit-plane search is bound by vector-ALU issue: 8 v_bitop3_b32 + 1 v_bcnt per 32 byte
+            # pairs.  How close it is to that roof, priced with the clock the chip held in this run
+            # (longest workgroup lifetime in shader cycles / launch duration).
+            me_ms = ms[vcs_hip.T_ME] / max(1, int(launches[vcs_hip.T_ME]))
+            valu_per_mb = 486.0
+            try:
+                kj = tj["kernels"]["k_me16b"]
+                valu_per_mb = round(kj["valu_wave_insts_per_dispatch"] / (tj["workload"]["frames_per_launch"] * N), 1)
+            except Exception:
+                pass
+            clock_ghz = state.get("clock_ghz") or None
+            core = (8 + 4.5) * 27                # 8 + 4.5 wave passes of 27 instructions per macroblock
+            out["k_me16b_valu_issue"] = {
+                "clock_ghz_measured": round(clock_ghz, 3) if clock_ghz else None,
+                "valu_wave_insts_per_macroblock": valu_per_mb,
+                "of_which_comparison_core": core,
+                "issue_cycles_per_macroblock": round(valu_per_mb * ISSUE_CYCLES_VOP3, 1),
+                "frac": (round(valu_per_mb * ISSUE_CYCLES_VOP3 * n0 * N / (1024 * clock_ghz * 1e9 * me_ms * 1e-3), 3)
+                         if clock_ghz else None),
+                "how": "vector wave-instructions per macroblock (PMC count in profiles/) x 4 issue cycles "
+                       "(VOP3, tools/ub_bits.hip) over 1,024 SIMDs x measured clock x launch time"}
         if me_name == "k_me16g":
             # The motion search is bound by vector-ALU issue, not by HBM: how close it is to THAT
             # roof, priced with the clock the chip held in this run (longest workgroup lifetime in
@@ -686,8 +726,7 @@ def main():
             out["resident_one_gop"] = {
                 "value": round(n_total * N * args.steps / dt1 / 1e3, 2), "unit": "macroblocks/ms",
                 "ms_per_step": round(dt1 / args.steps * 1e3, 4),
-                "kernel_ms_per_step": {"me": round(m1[vcs_hip.T_ME] / args.steps, 4),
-                                       "enc_tail": round(m1[vcs_hip.T_ENC_TAIL] / args.steps, 4)},
+                "kernel_ms_per_step": kernel_ms(m1, args.steps),
                 "note": "inputs re-read from the Infinity Cache every step; not the headline"}
     if rank == 0:
         if args.with_decode:

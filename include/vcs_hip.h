@@ -348,6 +348,10 @@ int vcs_timing(vcs_ctx *ctx, double *ms_out, uint64_t *launches_out, int n);
  * the last reset: divided by that launch's duration it is the clock the chip held under
  * this load (bench.py prices the kernel's vector-issue utilisation with it).            */
 int vcs_me_cycles(vcs_ctx *ctx, uint64_t *cycles, int reset);
+/* With timing on, the bit-plane search kernel (k_me16b) sums, over its workgroups, the shader-clock
+ * cycles (s_memtime) and the 100 MHz ticks (s_memrealtime) each of them lived: *ghz is their quotient,
+ * the clock the chip held under this load since the last reset (0 if the kernel has not run).        */
+int vcs_me_clock(vcs_ctx *ctx, double *ghz, int reset);
 /* Bytes/s of a device-to-device copy of `bytes` (the practical HBM roof).   */
 int vcs_measure_copy_bw(vcs_ctx *ctx, size_t bytes, int iters, double *gbps_out);
 /* Bytes/s of a device memset of `bytes` (the practical HBM write-only roof).  */

@@ -672,6 +672,53 @@ def test_gop_1080p_rolling_kernel(vh, oracle):
         assert np.array_equal(ns2[keep], ns[keep]) and np.array_equal(mv2[keep], mv[keep])
 
 
+@pytest.mark.parametrize("shape,n", [((360, 640), 7), ((200, 328), 13), ((1080, 1920), 9), ((48, 64), 6), ((144, 176), 33)])
+def test_bitplane_search_gop_batches(vh, oracle, shape, n):
+    """k_bits_ref / k_bits_cur / k_me16b (the default 16x16 search from 6 frames on): batches whose
+    frames are dealt to the waves unevenly (7; 13 = 7 + 6; 9 = 5 + 4; 33 = 7 + 7 + 7 + 6 + 6),
+    pictures with ragged right / bottom edges and fewer than 64 candidates per block, frames whose
+    blocks are mostly static, wholly static or not static at all, cost output on a single frame
+    batch, and the threshold variants (negative: nothing is static; huge: everything is)."""
+    from synth import synth_gop
+    H, W = shape
+    ref, frames = synth_gop(H, W, n, seed=31)
+    frames = np.ascontiguousarray(frames)
+    rng = np.random.default_rng(5)
+    for k in (1, 2):                                  # about 70 % / 40 % of the blocks (nearly) static
+        keep = rng.random((H // 16 + 1, W // 16 + 1)) < (0.7 if k == 1 else 0.4)
+        m = np.kron(keep, np.ones((16, 16), bool))[:H, :W]
+        noisy = np.clip(ref.astype(np.int16) + rng.integers(-1, 2, ref.shape), 0, 255).astype(np.uint8)
+        frames[k][m] = noisy[m]
+    frames[3] = ref                                   # every block static
+    frames[n - 1][: H // 2] = ref[: H // 2]          # the upper half static
+    with vh.Context(H, W, 16) as c:
+        c.gop_reserve(n)
+        c.gop_upload(0, frames)
+        for thresh in (2000, 0, 10 ** 9, -1):
+            c.set_params(sim_thresh=thresh)
+            c.set_ref(ref)
+            c.gop_encode(0, n)
+            mv, ns = c.gop_get_mv(0, n)
+            if thresh < 0:                            # nothing is static; frames without zero-difference
+                assert not ns.any()                   # blocks then equal the threshold-0 result
+                for k in (0, 4):
+                    omv, ons = oracle.me(frames[k], ref, 16, thresh=0)
+                    assert ons == 0 and np.array_equal(mv[k], omv), (thresh, k)
+                continue
+            for k in range(n):
+                omv, ons = oracle.me(frames[k], ref, 16, thresh=min(thresh, 2 ** 32 - 1))
+                assert np.array_equal(mv[k], omv), (thresh, k)
+                assert ns[k] == ons, (thresh, k)
+            if thresh == 2000:
+                assert ns[3] == c.N and ns[1] > 0.3 * c.N
+                _, oplanes, _ = oracle.encode_p(frames[n - 1], ref, 16)
+                assert np.array_equal(c.gop_get_planes(n - 1), oplanes)
+                # the same slots again: the static counters restart from zero
+                c.gop_encode(0, n)
+                mv2, ns2 = c.gop_get_mv(0, n)
+                assert np.array_equal(mv2, mv) and np.array_equal(ns2, ns)
+
+
 def test_forced_kernel_variants_subprocess():
     """The same parity cases with every specialised search kernel forced on small and
     ragged frames (VCS_ME16_ROLL=2 and friends), with them disabled (=0), with the generic
@@ -686,17 +733,22 @@ def test_forced_kernel_variants_subprocess():
     dct = "golden_dct_small or encode_decode_vs_oracle or dct_extremes or coeff_modes"
     # ROLL=2: the shared-window kernels (k_me16g, k_me8g) on every frame size; ROLL=2 with
     # GROUP=0: the private-window rolling kernel (k_me16r); ROLL=0: k_me16 / k_me8
-    for env_add, k in (({"VCS_ME16_ROLL": "2"}, sel),
-                       ({"VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "0", "VCS_ME8_GROUP": "0"}, sel),
-                       ({"VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "2", "VCS_ME16_WPS": "3"}, sel),
-                       ({"VCS_ME16_ROLL": "0"}, sel),
+    # BITS=2: the bit-plane search (k_bits_ref, k_bits_cur, k_me16b) on every 16x16 launch, single
+    # frames and ragged sizes included; BITS=0: never (the kernels below it run GOP-sized batches too)
+    for env_add, k in (({"VCS_ME16_BITS": "2"}, sel + " or gop_matches_single or bitplane"),
+                       ({"VCS_ME16_BITS": "2", "VCS_BITS_PF": "0"}, "gop_1080p_vs_oracle or gop_matches_single"),
+                       ({"VCS_ME16_BITS": "2", "VCS_L3_PREFETCH": "0"}, "gop_1080p_vs_oracle or gop_matches_single"),
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2"}, sel),
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "0", "VCS_ME8_GROUP": "0"}, sel),
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "2", "VCS_ME16_WPS": "3"}, sel),
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "0"}, sel),
                        ({"VCS_ME_GENERIC": "1"}, sel), ({"VCS_FAST_DIV": "0"}, dct),
                        # the tail kernels' other strip -> workgroup mappings (4 strips per workgroup)
                        ({"VCS_TAIL_MAP": "1"}, dct + " or gop_1080p_vs_oracle"),
                        ({"VCS_TAIL_MAP": "2"}, dct + " or gop_1080p_vs_oracle"),
                        # Infinity Cache prefetch as a separate pass / off (default: inside the search kernel)
-                       ({"VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "2"}, "gop_1080p_vs_oracle or gop_matches_single"),
-                       ({"VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "0"}, "gop_1080p_vs_oracle or gop_matches_single")):
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "2"}, "gop_1080p_vs_oracle or gop_matches_single"),
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "0"}, "gop_1080p_vs_oracle or gop_matches_single")):
         env = dict(os.environ, **env_add)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
                             "-m", "gpu", "-x", "-q", "-k", k, "-p", "no:cacheprovider"],

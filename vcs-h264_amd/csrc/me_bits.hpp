@@ -104,79 +104,87 @@ __global__ __launch_bounds__(256) void k_bits_ref(const uint8_t *__restrict__ re
 // cpl[((f * N + blk) * 8 + p) * 24 + 8 d + k]: row pair p of block blk of frame f as plane
 // dwords; binfo[f * N + blk] = {sum(max(ref - cur, 0)) over the co-located block, sum(cur)}
 // (motion.py:109-116, the static test, and the -sum(c) of the cost); n_static[f] += static
-// blocks.  A workgroup = 32 consecutive blocks of one frame: their 16 x 48-byte rows are
-// fetched as 16-byte pieces (with the co-located reference piece, for the static test) and
-// parked in LDS; then 768 (block, row pair, d) tasks, three per thread, transpose 32 bytes
-// each.  The frames are read whole-line by whole-line here, which also leaves them in the
-// Infinity Cache for the tail kernel.
+// blocks.  One thread per (block, row pair): its 96-byte string (2 rows x 48 bytes) as six
+// 16-byte pieces, the co-located reference pieces for the static test, three 32-byte
+// transposes, 96 contiguous bytes out (a workgroup = 32 blocks = 24 KB of planes in one
+// run).  The block sums meet in the 8 lanes of a block by DPP.
 constexpr int kBitsCurBlocks = 32;
 __global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ curs, size_t cur_stride,
-                                                  const uint8_t *__restrict__ ref, Geom g,
+                                                  const uint8_t *__restrict__ ref, Geom g, int n_frames,
                                                   uint32_t *__restrict__ cpl, uint2 *__restrict__ binfo,
                                                   uint32_t *__restrict__ n_static) {
-    __shared__ uint4 s_blk[kBitsCurBlocks * 48];    // [block][row][3 pieces]
-    __shared__ uint32_t s_acc[kBitsCurBlocks][3];   // sum|r - c|, sum r, sum c per block
     __shared__ uint32_t s_ns;
-    const int tid = threadIdx.x;
-    const int f = blockIdx.y;
-    const int blk0 = blockIdx.x * kBitsCurBlocks;
-    if (tid < kBitsCurBlocks * 3) (&s_acc[0][0])[tid] = 0;
+    __shared__ uint4 s_out[4 * 384];
+    const int tid = threadIdx.x, p = tid & 7;
+    // workgroups go round-robin to the 8 XCDs: XCD x takes the x-th eighth of every frame's blocks,
+    // frame after frame, so that its band of the reference (0.8 MB at 1080p) stays in its L2 while
+    // the frames stream through -- fetched anew per frame the co-located reference pieces are a
+    // third of the kernel's fabric traffic
+    const int per = (int)(gridDim.x >> 3) / n_frames;            // workgroups per XCD and frame
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int f = idx / per;
+    const int blockIdx_blk0 = (xcd * per + (idx - f * per)) * kBitsCurBlocks;
+    const int blk = blockIdx_blk0 + (tid >> 3);
     if (tid == 0) s_ns = 0;
     __syncthreads();
     const uint32_t fbytes = (uint32_t)(g.H * g.pitch);
     const __amdgpu_buffer_rsrc_t r_cur = buf_rsrc(curs + (size_t)f * cur_stride, fbytes);
     const __amdgpu_buffer_rsrc_t r_ref = buf_rsrc(ref, fbytes);
+    const int blkc = min(blk, g.N - 1);
+    const int byi = blkc / g.nbx, bxi = blkc - byi * g.nbx;
+    const uint32_t o = (uint32_t)((byi * 16 + 2 * p) * g.pitch + 48 * bxi);
     uint4 vc[6], vr[6];
 #pragma unroll
-    for (int it = 0; it < 6; it++) {   // 32 blocks x 16 rows x 3 pieces = 1,536 = 6 x 256
-        const int e = tid + 256 * it, bi = e / 48, r = e - bi * 48, row = r / 3, seg = r - row * 3;
-        const int blk = min(blk0 + bi, g.N - 1);
-        const int byi = blk / g.nbx, bxi = blk - byi * g.nbx;
-        const uint32_t o = (uint32_t)((byi * 16 + row) * g.pitch + 48 * bxi + 16 * seg);
-        vc[it] = buf_ld128(r_cur, o, 0);
-        vr[it] = buf_ld128(r_ref, o, 0);
+    for (int i = 0; i < 6; i++) {
+        const uint32_t oi = o + (i >= 3 ? (uint32_t)g.pitch + 16u * (i - 3) : 16u * i);
+        vc[i] = buf_ld128(r_cur, oi, 0);
+        vr[i] = buf_ld128(r_ref, oi, 0);
     }
+    uint32_t s[24], sad = 0, sr = 0, sc = 0;
 #pragma unroll
-    for (int it = 0; it < 6; it++) {
-        const int e = tid + 256 * it, bi = e / 48;
-        s_blk[e] = vc[it];
-        const uint32_t c4[4] = {vc[it].x, vc[it].y, vc[it].z, vc[it].w};
-        const uint32_t r4[4] = {vr[it].x, vr[it].y, vr[it].z, vr[it].w};
-        uint32_t sad = 0, sr = 0, sc = 0;
+    for (int i = 0; i < 6; i++) {
+        s[4 * i] = vc[i].x; s[4 * i + 1] = vc[i].y; s[4 * i + 2] = vc[i].z; s[4 * i + 3] = vc[i].w;
+        const uint32_t r4[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            sad = __builtin_amdgcn_sad_u8(r4[i], c4[i], sad);
-            sr = __builtin_amdgcn_sad_u8(r4[i], 0u, sr);
-            sc = __builtin_amdgcn_sad_u8(c4[i], 0u, sc);
+        for (int e = 0; e < 4; e++) {
+            sad = __builtin_amdgcn_sad_u8(r4[e], s[4 * i + e], sad);
+            sr = __builtin_amdgcn_sad_u8(r4[e], 0u, sr);
+            sc = __builtin_amdgcn_sad_u8(s[4 * i + e], 0u, sc);
         }
-        atomicAdd(&s_acc[bi][0], sad);
-        atomicAdd(&s_acc[bi][1], sr);
-        atomicAdd(&s_acc[bi][2], sc);
     }
-    __syncthreads();
+    // sum(max(r - c, 0)) = (sum|r - c| + sum r - sum c) / 2, over the 8 row pairs of the block
+    uint32_t sd2 = sad + sr - sc;
+    sd2 += dpp_u32<0xB1>(sd2); sd2 += dpp_u32<0x4E>(sd2); sd2 += dpp_u32<0x141>(sd2);
+    sc += dpp_u32<0xB1>(sc); sc += dpp_u32<0x4E>(sc); sc += dpp_u32<0x141>(sc);
+    const uint32_t sdiff = sd2 >> 1;
+    // a thread's 96 bytes are contiguous in cpl and so are the wave's 6 KB; they leave through LDS so
+    // that one store instruction writes 1 KB in a row (16-byte pieces 96 bytes apart are partial-line
+    // writes: 0.097 -> 0.0xx ms)
+    uint4 *const s_w = s_out + (tid >> 6) * 384;
+    const int lane = tid & 63;
 #pragma unroll
-    for (int it = 0; it < 3; it++) {   // 32 blocks x 8 row pairs x 3 string thirds = 768 = 3 x 256
-        const int e = tid + 256 * it, bi = e / 24, r = e - bi * 24, p = r / 3, d = r - p * 3;
-        const int blk = blk0 + bi;
-        // the 96-byte string of row pair p = pieces 0..5 of rows 2p, 2p + 1; third d = pieces 2d, 2d + 1
-        const uint4 lo = s_blk[bi * 48 + 6 * p + 2 * d], hi = s_blk[bi * 48 + 6 * p + 2 * d + 1];
-        uint32_t x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    for (int d = 0; d < 3; d++) {
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = s[8 * d + i];
         bits_transpose8(x);
-        if (blk < g.N) {
-            uint4 *dst = (uint4 *)(cpl + ((size_t)f * g.N + blk) * kBitsBlk + p * kBitsT + 8 * d);
-            dst[0] = make_uint4(x[0], x[1], x[2], x[3]);
-            dst[1] = make_uint4(x[4], x[5], x[6], x[7]);
+        s_w[lane * 6 + 2 * d] = make_uint4(x[0], x[1], x[2], x[3]);
+        s_w[lane * 6 + 2 * d + 1] = make_uint4(x[4], x[5], x[6], x[7]);
+    }
+    wave_lds_fence();
+    {
+        const int wblk0 = blockIdx_blk0 + (tid >> 6) * 8;   // first block of this wave
+        uint4 *dst = (uint4 *)(cpl + ((size_t)f * g.N + wblk0) * kBitsBlk);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int e = i * 64 + lane;                      // 16-byte piece of the wave's 8 blocks x 48 pieces
+            if (wblk0 + e / 48 < g.N) dst[e] = s_w[e];
         }
     }
-    if (tid < kBitsCurBlocks) {
-        const int blk = blk0 + tid;
-        if (blk < g.N) {
-            // sum(max(r - c, 0)) = (sum|r - c| + sum r - sum c) / 2
-            const uint32_t sdiff = (s_acc[tid][0] + s_acc[tid][1] - s_acc[tid][2]) >> 1;
-            binfo[(size_t)f * g.N + blk] = make_uint2(sdiff, s_acc[tid][2]);
-            if (!g.never_static && sdiff <= g.thresh) atomicAdd(&s_ns, 1u);
-        }
-    }
+    const bool head = p == 0 && blk < g.N;
+    if (head) binfo[(size_t)f * g.N + blk] = make_uint2(sdiff, sc);
+    const unsigned long long st = __ballot(head && !g.never_static && sdiff <= g.thresh);
+    if ((tid & 63) == 0 && st) atomicAdd(&s_ns, (uint32_t)__builtin_popcountll(st));
     __syncthreads();
     if (tid == 0 && s_ns) atomicAdd(&n_static[f], s_ns);
 }
@@ -226,13 +234,49 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                                                const uint2 *__restrict__ binfo, const uint32_t *__restrict__ sums,
                                                Geom g, int n_frames, int ngroups, int16_t *__restrict__ mv,
                                                unsigned long long *__restrict__ cost_out,
-                                               unsigned long long *__restrict__ clk_out) {
+                                               unsigned long long *__restrict__ clk_out,
+                                               const uint8_t *__restrict__ pf_base, uint32_t pf_total16,
+                                               int n_search_wgs, int pf_octets, int pf_ratio) {
     constexpr int BS = 16, WIN = 32, STEP = 5;
     using L = BitsLds<NF>;
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[4 * L::kWave];
+    // clk_out (timing on): shader-clock cycles and 100 MHz ticks this workgroup lived, summed over
+    // the workgroups: their quotient is the clock the chip held under this load
     const unsigned long long clk0 = clk_out ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long rt0 = clk_out ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Infinity Cache prefetch for the tail kernel (vcs_api.hip, k_l3_prefetch, explains why).  The
+    // workgroups behind the search's own are dispatched last, i.e. while the last generation of
+    // search workgroups drains and SIMDs fall idle: they stream the launch's P frames into LDS
+    // (LDS-direct, no register, no consumer) right before the tail wants them.  Earlier in the
+    // launch the lines would be gone again (the search moves 300 MB of planes and chunks).
+    // grid layout in octets (8 workgroups, one per XCD): `head` search octets, then pf_octets times
+    // [pf_ratio search octets, 1 prefetch octet]
+    int oct = (int)(blockIdx.x >> 3);
+    bool is_pf = false;
+    if (pf_octets) {
+        const int head = n_search_wgs / 8 - pf_ratio * pf_octets;
+        if (oct >= head) {
+            const int o2 = oct - head, grp = o2 / (pf_ratio + 1), r = o2 - grp * (pf_ratio + 1);
+            is_pf = r == pf_ratio;
+            oct = is_pf ? grp : head + grp * pf_ratio + r;
+        }
+    }
+    if (is_pf) {
+        const uint32_t nw = (uint32_t)pf_octets * 32u;
+        const uint32_t w = ((uint32_t)oct * 8u + (blockIdx.x & 7u)) * 4u + (uint32_t)wave;
+        const __amdgpu_buffer_rsrc_t r_pf = buf_rsrc(pf_base, pf_total16 << 4);
+        uint32_t it = 0;
+        for (uint32_t i = w * 64u; i < pf_total16; i += nw * 64u, it++) {   // uniform trip count
+            if (i + (uint32_t)lane < pf_total16)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    r_pf, (__attribute__((address_space(3))) void *)(s_lds + wave * 1024), 16,
+                    (int)((i + (uint32_t)lane) << 4), 0, 0, 0);
+            if ((it & 7u) == 7u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // at most 8 KB in flight per wave
+        }
+        return;
+    }
     uint8_t *const s_c = s_lds + wave * L::kWave;
     uint32_t *const s_part = (uint32_t *)(s_c + L::kPlanes);
     // units = (block position, frame group), column-major over the block positions (down a block
@@ -241,7 +285,7 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
     // one block position when ngroups = 4: they read the same chunks through one L1)
     const int total = g.N * ngroups;
     const int chunk = ((total + 7) / 8 + 3) & ~3;
-    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7, wg = oct;
     const int ul = wg * 4 + wave;
     const int u = xcd * chunk + ul;
     if (ul < chunk && u < total) {
@@ -434,7 +478,10 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
             if (cost_out) cost_out[o] = (unsigned long long)my_clo | ((unsigned long long)my_chi << 32);
         }
     }
-    if (clk_out && threadIdx.x == 0) atomicMax(clk_out, __builtin_amdgcn_s_memtime() - clk0);
+    if (clk_out && threadIdx.x == 0) {
+        atomicAdd(clk_out + 12, __builtin_amdgcn_s_memtime() - clk0);
+        atomicAdd(clk_out + 13, __builtin_amdgcn_s_memrealtime() - rt0);
+    }
 }
 
 // ---- host side ----------------------------------------------------------------------------
@@ -454,12 +501,18 @@ inline int me_bits_mode() {
     }();
     return v;
 }
-constexpr int kBitsMinFrames = 4;
+// Measured on MI355X (tools/gpu_bits_sizes.sh, whole step incl. k_bits_cur and the tables): 1080p,
+// n = 4: 0.212 vs 0.196 ms with k_me16g; n = 8: 0.290 vs 0.344; n = 29: 0.71 vs 0.87.  The chunk
+// table is 115 KB per picture row: 124 MB at 1080p; at 4K (497 MB, more than the Infinity Cache
+// holds) the search re-reads it from HBM per sub-batch and the step loses (3.8 vs 3.6 ms), so
+// frames that wide stay on k_me16g until the table is built per band of block columns.
+constexpr int kBitsMinFrames = 6;
+constexpr size_t kBitsMaxTable = (size_t)192 << 20;
 inline bool me_bits_worthwhile(const Geom &g, int n) {
     const int m = me_bits_mode();
     if (m == 0 || !me_fast_supported(g)) return false;
     if ((long long)g.N * n * kBitsBlk > 0x7FFFFFFFll * 4) return false;
-    return m == 2 || n >= kBitsMinFrames;
+    return m == 2 || (n >= kBitsMinFrames && me_bits_rtab_bytes(g) <= kBitsMaxTable);
 }
 inline int me_bits_groups(int n) { return (n + kBitsNF - 1) / kBitsNF; }
 
@@ -470,18 +523,31 @@ inline void launch_bits_ref(const Geom &g, hipStream_t stream, const uint8_t *re
 inline void launch_bits_cur(const Geom &g, hipStream_t stream, const uint8_t *curs, size_t stride, const uint8_t *ref,
                             int n, uint32_t *cpl, uint2 *binfo, uint32_t *ns, hipEvent_t ev_start = nullptr,
                             hipEvent_t ev_stop = nullptr) {
-    hipExtLaunchKernelGGL(k_bits_cur, dim3((g.N + kBitsCurBlocks - 1) / kBitsCurBlocks, n), dim3(256), 0, stream,
-                          ev_start, ev_stop, 0, curs, stride, ref, g, cpl, binfo, ns);
+    const int per = ((g.N + kBitsCurBlocks - 1) / kBitsCurBlocks + 7) / 8;   // workgroups per XCD and frame
+    hipExtLaunchKernelGGL(k_bits_cur, dim3(8 * per * n), dim3(256), 0, stream, ev_start, ev_stop, 0, curs, stride,
+                          ref, g, n, cpl, binfo, ns);
 }
 inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t *rtab, const uint32_t *cpl,
                                const uint2 *binfo, const uint32_t *sums, int n, int16_t *mv,
-                               unsigned long long *cost, unsigned long long *clk, hipEvent_t ev_start = nullptr,
-                               hipEvent_t ev_stop = nullptr) {
+                               unsigned long long *cost, unsigned long long *clk, const uint8_t *pf_base = nullptr,
+                               size_t pf_bytes = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     const int ngroups = me_bits_groups(n);
     const int total = g.N * ngroups;
     const int chunk = ((total + 7) / 8 + 3) & ~3;
-    hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(8 * (chunk / 4)), dim3(256), 0, stream, ev_start, ev_stop, 0,
-                          rtab, cpl, binfo, sums, g, n, ngroups, mv, cost, clk);
+    const int nsearch = 8 * (chunk / 4);
+    // prefetch workgroups: octets interleaved 1 : ratio with the last search octets (VCS_BITS_PF_WGS, VCS_BITS_PF_RATIO)
+    static const int npf_env = [] { const char *e = getenv("VCS_BITS_PF_WGS"); return e ? atoi(e) : 0; }();
+    static const int ratio_env = [] { const char *e = getenv("VCS_BITS_PF_RATIO"); return e ? atoi(e) : 0; }();
+    // measured (tools/gpu_pf_sweep.sh): lines prefetched more than ~30 us before the tail starts are
+    // gone again -- 256 workgroups, 1 : 1 behind the last search octets: tail 0.295 ms; the last 19 %
+    // of the launch (1 : 3, 512): 0.32; the last 60 %: 0.36 (= no prefetch)
+    const int ratio = ratio_env > 0 ? ratio_env : 1;
+    int pf8 = pf_base ? (npf_env > 0 ? npf_env : 256) / 8 : 0;
+    if (pf8 * ratio > nsearch / 8) pf8 = nsearch / 8 / ratio;
+    if (pf8 == 0) pf_base = nullptr;
+    hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(nsearch + 8 * pf8), dim3(256), 0, stream, ev_start, ev_stop, 0,
+                          rtab, cpl, binfo, sums, g, n, ngroups, mv, cost, clk, pf_base,
+                          (uint32_t)(pf_base ? pf_bytes >> 4 : 0), nsearch, pf8, ratio);
 }
 
 }  // namespace vcs

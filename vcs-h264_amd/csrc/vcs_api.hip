@@ -296,9 +296,18 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         launch_bits_cur(c->g, c->stream, curs, stride, ref, n, c->d_cpl, c->d_binfo, ns, evp.a, evp.b);
         if ((rc = t_end(c, &evp))) return rc;
         if ((rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/true))) return rc;
+        // The caller's Infinity Cache prefetch of the frames (vcs_gop_encode) rides at the END of the
+        // search launch (prefetch workgroups dispatched behind the search's own, me_bits.hpp).
+        // Measured alternatives, 29 x 1080p: k_bits_cur's own reads of the frames are gone from the
+        // cache when the tail starts (tail 0.37 instead of 0.29 ms: the search moves 300 MB of planes
+        // and chunks in between); so is a k_l3_prefetch started beside the search on a second stream;
+        // LDS-direct loads issued by every search wave on its way out: tail 0.35, search + 0.016 ms;
+        // a separate pass between search and tail: its own 0.04 ms.
+        static const bool pf_tail_wgs = [] { const char *e = getenv("VCS_BITS_PF"); return !(e && e[0] == '0'); }();
+        const bool pf = c->pf_in_search && pf_tail_wgs && (size_t)n * stride < 0xFFFFFFFFull;
         launch_bits_search(c->g, c->stream, c->d_rtab, c->d_cpl, c->d_binfo, c->d_sums, n, mv, cost,
-                           c->timing ? c->d_clk : nullptr, ev.a, ev.b);
-        // k_bits_cur has read the frames line by line: they are in the Infinity Cache for the tail
+                           c->timing ? c->d_clk : nullptr, pf ? curs : nullptr, (size_t)n * stride, ev.a, ev.b);
+        c->pf_in_search = pf;
         return t_end(c, &ev);
     }
     const bool fast16 = c->me_fast_ok && !force_generic;
@@ -1520,6 +1529,18 @@ int vcs_me_cycles(vcs_ctx *c, uint64_t *cycles, int reset) {
     HIP_TRY(c, hipMemcpy(&v, c->d_clk, 8, hipMemcpyDeviceToHost));
     *cycles = v;
     if (reset) HIP_TRY(c, hipMemset(c->d_clk, 0, 8));
+    return VCS_OK;
+}
+
+int vcs_me_clock(vcs_ctx *c, double *ghz, int reset) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (!ghz) return fail(c, VCS_E_ARG, "null pointer");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(v, c->d_clk + 12, 16, hipMemcpyDeviceToHost));
+    *ghz = v[1] ? (double)v[0] / (double)v[1] * 0.1 : 0.0;   // s_memrealtime ticks at 100 MHz
+    if (reset) HIP_TRY(c, hipMemset(c->d_clk + 12, 0, 16));
     return VCS_OK;
 }
 

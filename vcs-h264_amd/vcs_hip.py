@@ -103,6 +103,7 @@ SIGNATURES = {
     "vcs_timing_reset": (ctypes.c_int, [_c_ctx]),
     "vcs_timing": (ctypes.c_int, [_c_ctx, _f64p, _u64p, ctypes.c_int]),
     "vcs_me_cycles": (ctypes.c_int, [_c_ctx, _u64p, ctypes.c_int]),
+    "vcs_me_clock": (ctypes.c_int, [_c_ctx, _f64p, ctypes.c_int]),
     "vcs_measure_copy_bw": (ctypes.c_int, [_c_ctx, ctypes.c_size_t, ctypes.c_int, _f64p]),
     "vcs_measure_fill_bw": (ctypes.c_int, [_c_ctx, ctypes.c_size_t, ctypes.c_int, _f64p]),
 }
@@ -569,6 +570,12 @@ class Context:
     def me_cycles(self, reset=True):
         v = ctypes.c_uint64(0)
         self._ck(self._lib.vcs_me_cycles(self._h, ctypes.byref(v), int(bool(reset))))
+        return v.value
+
+    def me_clock(self, reset=True):
+        """GHz the chip held while k_me16b ran (timing on), 0.0 if it has not run."""
+        v = ctypes.c_double(0)
+        self._ck(self._lib.vcs_me_clock(self._h, ctypes.byref(v), int(bool(reset))))
         return v.value
 
     def measure_copy_bw(self, nbytes=1 << 30, iters=10):
