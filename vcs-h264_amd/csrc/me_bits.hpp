@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void k_bits_ref(const uint8_t *__restrict__ re
 // ---- current blocks -----------------------------------------------------------------------
 // cpl[((f * N + blk) * 8 + p) * 24 + 8 d + k]: row pair p of block blk of frame f as plane
 // dwords; binfo[f * N + blk] = {sum(max(ref - cur, 0)) over the co-located block, sum(cur)}
-// (motion.py:109-116, the static test, and the -sum(c) of the cost); n_static[f] += static
-// blocks.  One thread per (block, row pair): its 96-byte string (2 rows x 48 bytes) as six
+// (motion.py:109-116, the static test, and the -sum(c) of the cost); ns_part[f][workgroup] =
+// static blocks.  One thread per (block, row pair): its 96-byte string (2 rows x 48 bytes) as six
 // 16-byte pieces, the co-located reference pieces for the static test, three 32-byte
 // transposes, 96 contiguous bytes out (a workgroup = 32 blocks = 24 KB of planes in one
 // run).  The block sums meet in the 8 lanes of a block by DPP.
@@ -112,7 +112,7 @@ constexpr int kBitsCurBlocks = 32;
 __global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ curs, size_t cur_stride,
                                                   const uint8_t *__restrict__ ref, Geom g, int n_frames,
                                                   uint32_t *__restrict__ cpl, uint2 *__restrict__ binfo,
-                                                  uint32_t *__restrict__ n_static) {
+                                                  uint32_t *__restrict__ ns_part) {
     __shared__ uint32_t s_ns;
     __shared__ uint4 s_out[4 * 384];
     const int tid = threadIdx.x, p = tid & 7;
@@ -186,7 +186,9 @@ __global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ cu
     const unsigned long long st = __ballot(head && !g.never_static && sdiff <= g.thresh);
     if ((tid & 63) == 0 && st) atomicAdd(&s_ns, (uint32_t)__builtin_popcountll(st));
     __syncthreads();
-    if (tid == 0 && s_ns) atomicAdd(&n_static[f], s_ns);
+    // static blocks of this workgroup; k_me16b adds the 8 * per counts of a frame up (no counter to
+    // zero before the launch, no atomics on it)
+    if (tid == 0) ns_part[(size_t)f * (8 * per) + xcd * per + (idx - f * per)] = s_ns;
 }
 
 // ---- the search ---------------------------------------------------------------------------
@@ -236,7 +238,9 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                                                unsigned long long *__restrict__ cost_out,
                                                unsigned long long *__restrict__ clk_out,
                                                const uint8_t *__restrict__ pf_base, uint32_t pf_total16,
-                                               int n_search_wgs, int pf_octets, int pf_ratio) {
+                                               int n_search_wgs, int pf_octets, int pf_ratio,
+                                               const uint32_t *__restrict__ ns_part, int ns_per_frame,
+                                               uint32_t *__restrict__ n_static) {
     constexpr int BS = 16, WIN = 32, STEP = 5;
     using L = BitsLds<NF>;
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[4 * L::kWave];
@@ -285,6 +289,14 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
     // one block position when ngroups = 4: they read the same chunks through one L1)
     const int total = g.N * ngroups;
     const int chunk = ((total + 7) / 8 + 3) & ~3;
+    if (blockIdx.x == 0) {   // static blocks per frame: the sums of k_bits_cur's per-workgroup counts
+        for (int f = wave; f < n_frames; f += 4) {
+            uint32_t v = 0;
+            for (int i = lane; i < ns_per_frame; i += 64) v += ns_part[(size_t)f * ns_per_frame + i];
+            v = wave_sum_u32(v);
+            if (lane == 0) n_static[f] = v;
+        }
+    }
     const int xcd = blockIdx.x & 7, wg = oct;
     const int ul = wg * 4 + wave;
     const int u = xcd * chunk + ul;
@@ -489,7 +501,9 @@ constexpr int kBitsNF = 8;   // frames per wave the search kernel is unrolled fo
 
 inline size_t me_bits_rtab_bytes(const Geom &g) { return (size_t)g.H * g.nbx * kBitsWA * 4 + 256; }
 inline size_t me_bits_cpl_bytes(const Geom &g, int n) { return (size_t)n * g.N * kBitsBlk * 4; }
-inline size_t me_bits_binfo_bytes(const Geom &g, int n) { return (size_t)n * g.N * sizeof(uint2); }
+inline size_t me_bits_binfo_bytes(const Geom &g, int n) {   // {static-test sum, sum(c)} per block + the static counts per workgroup
+    return (size_t)n * g.N * sizeof(uint2) + (size_t)n * (8 * (((g.N + 31) / 32 + 7) / 8)) * sizeof(uint32_t);
+}
 
 // VCS_ME16_BITS: 0 = off (k_me16g / k_me16r / k_me16), 1 = default (batches of >= kBitsMinFrames
 // frames), 2 = every launch (tests run small and ragged frames through it).
@@ -520,16 +534,18 @@ inline void launch_bits_ref(const Geom &g, hipStream_t stream, const uint8_t *re
     const uint32_t total = (uint32_t)g.H * (uint32_t)g.nbx * kBitsM;
     hipLaunchKernelGGL(k_bits_ref, dim3((total + 255) / 256), dim3(256), 0, stream, ref, (uint32_t)ref_bytes, g, rtab);
 }
+inline int me_bits_cur_wgs(const Geom &g) {   // workgroups of k_bits_cur per frame (a multiple of 8)
+    return 8 * (((g.N + kBitsCurBlocks - 1) / kBitsCurBlocks + 7) / 8);
+}
 inline void launch_bits_cur(const Geom &g, hipStream_t stream, const uint8_t *curs, size_t stride, const uint8_t *ref,
-                            int n, uint32_t *cpl, uint2 *binfo, uint32_t *ns, hipEvent_t ev_start = nullptr,
+                            int n, uint32_t *cpl, uint2 *binfo, uint32_t *ns_part, hipEvent_t ev_start = nullptr,
                             hipEvent_t ev_stop = nullptr) {
-    const int per = ((g.N + kBitsCurBlocks - 1) / kBitsCurBlocks + 7) / 8;   // workgroups per XCD and frame
-    hipExtLaunchKernelGGL(k_bits_cur, dim3(8 * per * n), dim3(256), 0, stream, ev_start, ev_stop, 0, curs, stride,
-                          ref, g, n, cpl, binfo, ns);
+    hipExtLaunchKernelGGL(k_bits_cur, dim3(me_bits_cur_wgs(g) * n), dim3(256), 0, stream, ev_start, ev_stop, 0, curs,
+                          stride, ref, g, n, cpl, binfo, ns_part);
 }
 inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t *rtab, const uint32_t *cpl,
-                               const uint2 *binfo, const uint32_t *sums, int n, int16_t *mv,
-                               unsigned long long *cost, unsigned long long *clk, const uint8_t *pf_base = nullptr,
+                               const uint2 *binfo, const uint32_t *sums, int n, int16_t *mv, const uint32_t *ns_part,
+                               uint32_t *ns, unsigned long long *cost, unsigned long long *clk, const uint8_t *pf_base = nullptr,
                                size_t pf_bytes = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     const int ngroups = me_bits_groups(n);
     const int total = g.N * ngroups;
@@ -547,7 +563,7 @@ inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t
     if (pf8 == 0) pf_base = nullptr;
     hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(nsearch + 8 * pf8), dim3(256), 0, stream, ev_start, ev_stop, 0,
                           rtab, cpl, binfo, sums, g, n, ngroups, mv, cost, clk, pf_base,
-                          (uint32_t)(pf_base ? pf_bytes >> 4 : 0), nsearch, pf8, ratio);
+                          (uint32_t)(pf_base ? pf_bytes >> 4 : 0), nsearch, pf8, ratio, ns_part, me_bits_cur_wgs(g), ns);
 }
 
 }  // namespace vcs

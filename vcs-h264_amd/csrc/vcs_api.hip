@@ -273,7 +273,7 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     const bool bits = c->me_fast_ok && !force_generic && me_bits_worthwhile(c->g, n);
     // the per-frame static-block counters start at zero; the rolling kernel's primer does it
     const bool roll = !bits && c->me_fast_ok && !force_generic && me16r_worthwhile(c->g, c->cus, n);
-    if (!roll) HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
+    if (!roll && !bits) HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
     // per-reference sum(r) table, once per reference frame (all P frames of a GOP share it);
     // not part of VCS_T_ME, which times the search kernel alone
     if (!c->sums_valid && !force_generic && (c->me_fast_ok || c->me_fast8_ok)) {
@@ -293,7 +293,8 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         }
         EvPair evp, ev;
         if ((rc = t_begin(c, VCS_T_ME_PREP, &evp, /*attach=*/true))) return rc;
-        launch_bits_cur(c->g, c->stream, curs, stride, ref, n, c->d_cpl, c->d_binfo, ns, evp.a, evp.b);
+        uint32_t *ns_part = (uint32_t *)(c->d_binfo + (size_t)n * c->g.N);   // behind the n * N block records
+        launch_bits_cur(c->g, c->stream, curs, stride, ref, n, c->d_cpl, c->d_binfo, ns_part, evp.a, evp.b);
         if ((rc = t_end(c, &evp))) return rc;
         if ((rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/true))) return rc;
         // The caller's Infinity Cache prefetch of the frames (vcs_gop_encode) rides at the END of the
@@ -305,7 +306,7 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         // a separate pass between search and tail: its own 0.04 ms.
         static const bool pf_tail_wgs = [] { const char *e = getenv("VCS_BITS_PF"); return !(e && e[0] == '0'); }();
         const bool pf = c->pf_in_search && pf_tail_wgs && (size_t)n * stride < 0xFFFFFFFFull;
-        launch_bits_search(c->g, c->stream, c->d_rtab, c->d_cpl, c->d_binfo, c->d_sums, n, mv, cost,
+        launch_bits_search(c->g, c->stream, c->d_rtab, c->d_cpl, c->d_binfo, c->d_sums, n, mv, ns_part, ns, cost,
                            c->timing ? c->d_clk : nullptr, pf ? curs : nullptr, (size_t)n * stride, ev.a, ev.b);
         c->pf_in_search = pf;
         return t_end(c, &ev);
