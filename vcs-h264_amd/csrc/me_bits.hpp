@@ -192,20 +192,35 @@ __global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ cu
 }
 
 // ---- the search ---------------------------------------------------------------------------
-// One comparison step of the borrow chain on 32 pairs: r < c so far (b), planes r, c.
+// One comparison step of the borrow chain on 32 pairs: r < c so far (b), planes r, c:
+// b' = majority(c, b, ~r) -- r != c: c decides (c = 1, r = 0: r < c); r == c: keep b.
+// v_bitop3_b32 with truth table 0xD4 (bit index = src0 * 4 + src1 * 2 + src2).
 __device__ __forceinline__ uint32_t bits_lt_step(uint32_t r, uint32_t c, uint32_t b) {
-    const uint32_t x = r ^ c;          // selects to ONE v_bitop3_b32 with the line below
-    return (x & c) | (~x & b);         // r != c: c decides (c = 1, r = 0: r < c); r == c: keep
+    return __builtin_amdgcn_bitop3_b32(c, b, r, 0xD4);
 }
-// #{r < c} over the 96 byte pairs of one chunk: 3 dwords x 8 planes, t = 8 d + k
-__device__ __forceinline__ uint32_t bits_count_lt(const uint32_t (&r)[kBitsT], const uint32_t (&c)[kBitsT]) {
-    uint32_t n = 0;
+// #{r < c} over the 96 byte pairs of one chunk: 3 dwords x 8 planes, t = 8 d + k; added to n
+__device__ __forceinline__ uint32_t bits_count_lt(const uint32_t (&r)[kBitsT], const uint32_t (&c)[kBitsT], uint32_t n) {
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        uint32_t b = c[8 * d] & ~r[8 * d];   // plane 0: r < c iff r = 0, c = 1
+        uint32_t b = 0;
 #pragma unroll
-        for (int k = 1; k < 8; k++) b = bits_lt_step(r[8 * d + k], c[8 * d + k], b);
-        n += (uint32_t)__builtin_popcount(b);
+        for (int k = 0; k < 8; k++) b = bits_lt_step(r[8 * d + k], c[8 * d + k], b);
+        n = (uint32_t)__builtin_popcount(b) + n;   // one v_bcnt_u32_b32 (x, acc) ...
+        asm volatile("" : "+v"(n));                // ... not v_bcnt(x, 0) + v_add3: the chain stays
+    }
+    return n;
+}
+// the same with the first step of the first chain already taken (b0): the search kernel puts its
+// next loads between that step and the rest
+__device__ __forceinline__ uint32_t bits_count_lt_from(const uint32_t (&r)[kBitsT], const uint32_t (&c)[kBitsT],
+                                                      uint32_t b0, uint32_t n) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        uint32_t b = d == 0 ? b0 : 0u;
+#pragma unroll
+        for (int k = d == 0 ? 1 : 0; k < 8; k++) b = bits_lt_step(r[8 * d + k], c[8 * d + k], b);
+        n = (uint32_t)__builtin_popcount(b) + n;
+        asm volatile("" : "+v"(n));
     }
     return n;
 }
@@ -225,10 +240,11 @@ __device__ __forceinline__ void bits_group(int n, int ngroups, int grp, int &f0,
 }
 
 // LDS of one wave: the planes of its NF current blocks, [row pair][frame][96 bytes] (filled by
-// LDS-direct loads, one per row pair), and the second pass's counts, [frame][40]
+// LDS-direct loads, one per row pair), and the second pass's counts, [frame pair][40] (two 16-bit
+// counts per word: a count is at most 768) -- 6,784 bytes at NF = 8: six workgroups per CU
 template <int NF>
 struct BitsLds {
-    static constexpr int kPlanes = 8 * NF * 96, kPart = NF * 40 * 4, kWave = kPlanes + kPart;
+    static constexpr int kPlanes = 8 * NF * 96, kPart = ((NF + 1) / 2) * 40 * 4, kWave = kPlanes + kPart;
 };
 
 template <int NF>
@@ -315,18 +331,14 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
         const int ncand = nci * ncj;
         const uint32_t inv_ncj = ncj ? 65536u / (uint32_t)ncj + 1u : 0u;   // cand / ncj for cand < 128, ncj <= 10
 
-        // per frame: static? (scalar)
-        uint32_t sdiff[NF], sumc[NF];
+        // per frame: static? (scalar; the records are read again at the end rather than kept: 16
+        // SGPRs the loops below would otherwise spill around)
         uint32_t skip = 0;   // bit f: nothing to search for frame f0 + f
 #pragma unroll
         for (int f = 0; f < NF; f++) {
-            sdiff[f] = 0;
-            sumc[f] = 0;
             if (f < nf) {
-                const uint2 bi = binfo[(size_t)(f0 + f) * g.N + blk];
-                sdiff[f] = bi.x;
-                sumc[f] = bi.y;
-                if (!g.never_static && bi.x <= g.thresh) skip |= 1u << f;
+                const uint32_t sd = binfo[(size_t)(f0 + f) * g.N + blk].x;
+                if (!g.never_static && sd <= g.thresh) skip |= 1u << f;
             } else {
                 skip |= 1u << f;
             }
@@ -373,19 +385,28 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                 // one round = one row pair: the chunk of the round is in `cur`; the next round's chunk
                 // and the planes two rounds ahead are requested behind the first frame (the wait that
                 // frame's first use of `cur` draws covers everything issued a round ago, nothing newer)
+                // Frames go in pairs: the planes of both (2 x 24 SGPRs) are requested together and
+                // waited for once -- a scalar load that hits L2 still takes a few hundred cycles and a
+                // wave has nothing else to do meanwhile; per pair the wait is paid once.  A pair is
+                // compared if either frame is searched (the other one's counts are never used).
                 auto round = [&](const uint32_t (&cur)[kBitsT], uint32_t (&nxt)[kBitsT], int p, bool has_next) {
-#pragma unroll
-                    for (int f = 0; f < NF; f++) {
-                        if (!((skip >> f) & 1u)) {   // scalar branch
+                    auto planes = [&](uint32_t (&cs)[kBitsT], int f) {
 #ifdef VCS_EXP_BITS_SAMEC   // experiment builds only (results are wrong): every plane load hits the scalar cache
-                            const uint32_t *__restrict__ c = cblk + (f & 1) * kBitsT;
+                        const uint32_t *__restrict__ c = cblk + (f & 1) * kBitsT;
 #else
-                            const uint32_t *__restrict__ c = cblk + (size_t)f * cfs + p * kBitsT;
+                        const uint32_t *__restrict__ c = cblk + (size_t)min(f, nf - 1) * cfs + p * kBitsT;
 #endif
-                            uint32_t cs[kBitsT];
 #pragma unroll
-                            for (int t = 0; t < kBitsT; t++) cs[t] = c[t];
-                            acc[f] += bits_count_lt(cur, cs);
+                        for (int t = 0; t < kBitsT; t++) cs[t] = c[t];
+                    };
+#pragma unroll
+                    for (int f = 0; f < NF; f += 2) {
+                        if (((skip >> f) & 3u) != 3u) {   // scalar branch
+                            uint32_t ca[kBitsT], cb[kBitsT];
+                            planes(ca, f);
+                            if (f + 1 < NF) planes(cb, f + 1);
+                            acc[f] = bits_count_lt(cur, ca, acc[f]);
+                            if (f + 1 < NF) acc[f + 1] = bits_count_lt(cur, cb, acc[f + 1]);
                         }
                         if (f == 0) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -416,7 +437,7 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                 const uint32_t inv_n2 = 65536u / (uint32_t)n2 + 1u;   // t / n2 for t < 288, n2 <= 36
                 if (lane < 40) {
 #pragma unroll
-                    for (int f = 0; f < NF; f++) s_part[f * 40 + lane] = 0;
+                    for (int f = 0; f < (NF + 1) / 2; f++) s_part[f * 40 + lane] = 0;
                 }
                 // the LDS-direct loads have landed (this wave's own: its vmcnt is what orders them)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -440,8 +461,8 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                                 const uint4 v = cq[f * 6 + q];
                                 cs[4 * q] = v.x; cs[4 * q + 1] = v.y; cs[4 * q + 2] = v.z; cs[4 * q + 3] = v.w;
                             }
-                            const uint32_t cnt = bits_count_lt(r, cs);
-                            if (act) atomicAdd(&s_part[f * 40 + ck], cnt);
+                            const uint32_t cnt = bits_count_lt(r, cs, 0u);
+                            if (act) atomicAdd(&s_part[(f >> 1) * 40 + ck], cnt << (16 * (f & 1)));
                         }
                     }
                 }
@@ -450,7 +471,8 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                     const uint32_t sr2 = sums[(size_t)blk * kMe16SumStride + 64 + lane];
 #pragma unroll
                     for (int f = 0; f < NF; f++)
-                        best[f] = min(best[f], ((sr2 + 256u * s_part[f * 40 + lane]) << 7) | (uint32_t)(64 + lane));
+                        best[f] = min(best[f], ((sr2 + 256u * ((s_part[(f >> 1) * 40 + lane] >> (16 * (f & 1))) & 0xFFFFu)) << 7) |
+                                               (uint32_t)(64 + lane));
                 }
                 wave_lds_fence();   // the next unit would rewrite s_part (one unit per wave today)
             }
@@ -461,9 +483,10 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             if (f < nf) {
+                const uint2 bi = binfo[(size_t)(f0 + f) * g.N + blk];
                 uint32_t mvw = 0u;
-                unsigned long long cw = sdiff[f];      // static block: [0, 0], cost = the difference
-                const bool is_static = !g.never_static && sdiff[f] <= g.thresh;
+                unsigned long long cw = bi.x;          // static block: [0, 0], cost = the difference
+                const bool is_static = (skip >> f) & 1u;
                 if (!is_static) {
                     const uint32_t key = wave_min_u32(best[f]);
                     int bx = 0, byy = 0;
@@ -473,7 +496,7 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                         const int cbi = (int)(((uint32_t)cb * inv_ncj) >> 16);
                         byy = i_min + cbi * STEP;
                         bx = j_min + (cb - cbi * ncj) * STEP;
-                        cw = (key >> 7) - sumc[f];
+                        cw = (key >> 7) - bi.y;
                     }
                     mvw = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);  // [dx, dy]
                 }
@@ -497,7 +520,10 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
 }
 
 // ---- host side ----------------------------------------------------------------------------
-constexpr int kBitsNF = 8;   // frames per wave the search kernel is unrolled for
+#ifndef VCS_BITS_NF
+#define VCS_BITS_NF 8
+#endif
+constexpr int kBitsNF = VCS_BITS_NF;   // frames per wave the search kernel is unrolled for
 
 inline size_t me_bits_rtab_bytes(const Geom &g) { return (size_t)g.H * g.nbx * kBitsWA * 4 + 256; }
 inline size_t me_bits_cpl_bytes(const Geom &g, int n) { return (size_t)n * g.N * kBitsBlk * 4; }
