@@ -45,6 +45,8 @@ for p in (REPO, PKG, os.path.join(PKG, "InterframeCompression")):
 
 import numpy as np  # noqa: E402
 
+INIT_TIMEOUT_S = float(os.environ.get("VCS_BENCH_INIT_TIMEOUT_S", "60"))   # RCCL bring-up / file rendezvous
+state_stuck = {}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~5500 measured copy
 # issue cycles per wave-instruction on one SIMD, measured on this chip by tools/ub_valu.hip
 ISSUE_CYCLES = {"v_lerp_u8": 4, "v_and_b32": 2, "v_bcnt_u32_b32": 4, "other": 4}
@@ -451,17 +453,34 @@ def main():
     launched = "RANK" in os.environ          # under torch.distributed.run (or any launcher)
     if use_group:
         if world > 1 or launched:            # one process per GPU: ncclCommInitRank
-            err = ""
-            try:
-                uid = vcs_hip.rendezvous_unique_id(rank, world)
-                group = vcs_hip.Group.from_rank(ctx, uid, world, rank)
-                group.barrier()
-            except Exception as e:           # noqa: BLE001 -- anything RCCL / the rendezvous raises
-                err, group = repr(e), None
+            # ncclCommInitRank and the first barrier block until EVERY rank has joined: if only some
+            # ranks fail, the others would sit there for ever.  They run in a thread that is given the
+            # file rendezvous' time; a rank still inside after that reports a time-out, all ranks fall
+            # back together, and the process leaves through os._exit at the end (the thread is stuck).
+            import threading
+            box = {}
+
+            def bring_up():
+                try:
+                    uid = vcs_hip.rendezvous_unique_id(rank, world, timeout_s=INIT_TIMEOUT_S)
+                    g_ = vcs_hip.Group.from_rank(ctx, uid, world, rank)
+                    g_.barrier()
+                    box["group"] = g_
+                except Exception as e:       # noqa: BLE001 -- anything RCCL / the rendezvous raises
+                    box["err"] = repr(e)
+            th = threading.Thread(target=bring_up, daemon=True)
+            th.start()
+            th.join(INIT_TIMEOUT_S + 5.0)
+            err, group = "", box.get("group")
+            if th.is_alive():
+                err, group = "timed out after %.0f s in the RCCL set-up (another rank never joined)" % INIT_TIMEOUT_S, None
+                state_stuck["thread"] = True
+            elif "err" in box:
+                err, group = box["err"], None
             if world > 1:
                 # the ranks agree (through files, RCCL being what is in doubt) whether ALL of them
                 # have a communicator; if not, all take the no-collective fall-back
-                fsync = _FileSync(rank, world, vcs_hip._job_tag())
+                fsync = _FileSync(rank, world, vcs_hip._job_tag(), timeout_s=INIT_TIMEOUT_S + 30.0)
                 errs = [e for e in fsync.exchange(err) if e]
                 if errs:
                     if group is not None:
@@ -635,7 +654,9 @@ def main():
             "value": round(value, 2), "unit": "macroblocks/ms",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "higher_is_better": True,
+            # the no-collective fall-back is not a point of a scaling curve: say so where a driver looks
+            "scaling": None if rccl_failed else ("strong" if args.strong else "weak"), "vs_baseline": None,
             "dtype": "u8 (motion search) + f64 (DCT)", "data": "synthetic",
             "config": {"workload": wl,
                        "frames_per_step_gpu0": n0, "frames_per_step_total": n_total,
@@ -650,6 +671,7 @@ def main():
                                        "uploaded the I frame itself and kept its vectors, ranks met through "
                                        "files" % rccl_failed if rccl_failed else
                                        "in-library RCCL broadcast (I frame) + all-gather (vectors) per GOP: " + transport)},
+            **({"degraded": "no_collectives"} if rccl_failed else {}),
             "clock_conditioning": {"untimed_steps_before_the_warmup": cond_steps,
                                    "why": "the timed steps run at the sustained clock; VCS_BENCH_CONDITION_MS=0 turns it off"},
             "idle_start_first_pass": first_pass,
@@ -772,6 +794,9 @@ def main():
                 out["coeff_modes"] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if state_stuck:        # a bring-up thread is still inside RCCL: it cannot be joined
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

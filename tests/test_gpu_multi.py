@@ -199,6 +199,19 @@ def test_async_slots_vs_oracle(vh, oracle):
         mv, ns = c.wait(1)
         assert np.array_equal(mv, oracle.me(frames[2], frames[1], bs)[0])
         del h, h2
+        # strided views: the upload reads a contiguous copy that only the context keeps alive
+        # until wait() -- the temporaries are dropped here before the copies have to finish
+        import gc
+        c.set_ref(ref)
+        for k in range(3):
+            c.encode_p_async(k, frames[k][:, ::-1])
+        gc.collect()
+        junk = [np.full((H, W, 3), 250 - 30 * k, np.uint8) for k in range(8)]   # reuses freed memory, if any
+        for k in range(3):
+            mv, ns = c.wait(k)
+            omv, ons = oracle.me(np.ascontiguousarray(frames[k][:, ::-1]), ref, bs)
+            assert np.array_equal(mv, omv) and ns == ons, k
+        del junk
 
 
 def test_pipelined_encoder_dropin(vh, oracle, capsys):
@@ -306,3 +319,5 @@ def test_bench_rank_path_falls_back_without_rccl(tmp_path):
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["config"]["frames_per_step_total"] == 6
     assert "FALL-BACK" in line["config"]["collectives"]
+    # ... and where a driver that only reads the top level looks: not a point of a scaling curve
+    assert line["degraded"] == "no_collectives" and line["scaling"] is None

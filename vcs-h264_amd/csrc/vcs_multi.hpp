@@ -52,7 +52,7 @@ struct vcs_group {
     uint8_t *d_iframe = nullptr;  // on shard 0's device: the staged I frame of the next GOP
     hipEvent_t ev_iframe = nullptr;
     bool iframe_valid = false;
-    uint8_t *d_word = nullptr;    // per[0]'s device: 8 bytes for barrier / max reductions
+    uint8_t *d_word = nullptr;    // per[0]'s device: 64 bytes for barrier / max reductions and the parameter-hash check
     std::vector<uint8_t> host;    // D2H staging of the gathered vectors
     std::string err;
 };
@@ -133,14 +133,29 @@ int group_init_common(vcs_group *g) {
     }
     vcs_ctx *c0 = g->per[0].c;
     G_HIP(g, hipSetDevice(c0->device));
-    G_HIP(g, hipMalloc(&g->d_word, 16));
-    G_HIP(g, hipMemset(g->d_word, 0, 16));
+    G_HIP(g, hipMalloc(&g->d_word, 64));
+    G_HIP(g, hipMemset(g->d_word, 0, 64));
     if (g->rank0 == 0) {
         G_HIP(g, hipMalloc(&g->d_iframe, c0->Fs));
         G_HIP(g, hipMemset(g->d_iframe, 0, c0->Fs));
         G_HIP(g, hipEventCreateWithFlags(&g->ev_iframe, hipEventDisableTiming));
     }
     return VCS_OK;
+}
+
+// Everything that decides a shard's results: geometry, search parameters, threshold, search / cost
+// selectors, coefficient mode and the three quantiser tables (FNV-1a).
+uint64_t group_param_hash(const vcs_ctx *c) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    const int v[9] = {c->g.H, c->g.W, c->g.bs, c->g.win, c->g.step, c->coeff_mode, c->search, c->cost, 0};
+    mix(v, sizeof v);
+    mix(&c->thresh64, sizeof c->thresh64);
+    mix(c->hDQ + 64, sizeof(double) * 192);
+    return h;
 }
 
 int group_check_same_geometry(vcs_group *g, vcs_ctx *const *ctxs, int n) {
@@ -150,6 +165,8 @@ int group_check_same_geometry(vcs_group *g, vcs_ctx *const *ctxs, int n) {
         if (a.H != b.H || a.W != b.W || a.bs != b.bs || a.win != b.win || a.step != b.step ||
             ctxs[0]->coeff_mode != ctxs[i]->coeff_mode)
             return gfail(g, VCS_E_ARG, "context %d differs from context 0 in geometry / parameters", i);
+        if (group_param_hash(ctxs[0]) != group_param_hash(ctxs[i]))
+            return gfail(g, VCS_E_ARG, "context %d differs from context 0 in threshold / search / cost / Q tables", i);
         for (int j = 0; j < i; j++)
             if (ctxs[j] == ctxs[i]) return gfail(g, VCS_E_ARG, "context %d listed twice", i);
     }
@@ -430,6 +447,26 @@ int vcs_group_layout_sets(vcs_group *g, int n_p_frames, int with_decode, int n_s
     int rc = group_sync_all(g);
     if (rc) return rc;
     group_free_buffers(g);
+    // differently configured shards would encode silently: the parameter block of every shard
+    // (every process's too: max and min of its hash through the communicator) must be the same
+    {
+        std::vector<vcs_ctx *> cs;
+        for (auto &p : g->per) cs.push_back(p.c);
+        if ((rc = group_check_same_geometry(g, cs.data(), (int)cs.size()))) return rc;
+        if (g->rccl && g->world != (int)g->per.size()) {
+            auto &p0 = g->per[0];
+            const uint64_t h = group_param_hash(p0.c);
+            uint64_t pair[2] = {h, ~h}, red[2] = {0, 0};
+            G_HIP(g, hipSetDevice(p0.c->device));
+            G_HIP(g, hipMemcpy(g->d_word, pair, 16, hipMemcpyHostToDevice));
+            G_NCCL(g, ncclAllReduce(g->d_word, g->d_word + 16, 2, ncclUint64, ncclMax, p0.comm, p0.cs));
+            G_HIP(g, hipStreamSynchronize(p0.cs));
+            G_HIP(g, hipMemcpy(red, g->d_word + 16, 16, hipMemcpyDeviceToHost));
+            if (red[0] != h || red[1] != ~h)   // max(h) and max(~h) = ~min(h): all equal iff both are mine
+                return gfail(g, VCS_E_ARG, "the shards' parameters differ across processes (geometry, search "
+                                           "window / stride / threshold, search / cost selectors, coefficient mode or Q tables)");
+        }
+    }
     g->n_p = n_p_frames;
     g->sets = n_sets;
     g->set = 0;

@@ -11,6 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+_T_START = __import__("time").time()   # this process's start, for the rendezvous file's freshness test
 LIB_PATH = os.environ.get("VCS_HIP_LIB") or os.path.join(_HERE, "lib", "libvcs_hip.so")
 
 VCS_COEFF_F64, VCS_COEFF_F32, VCS_COEFF_I16 = 0, 1, 2
@@ -432,12 +433,20 @@ class Context:
         h = _vp()
         self._ck(self._lib.vcs_encode_p_async(self._h, int(slot), cur.ctypes.data_as(_u8p),
                                               ctypes.byref(h)))
+        # the buffer the upload reads (a fresh contiguous copy when the caller passed a strided view)
+        # lives until wait(slot): the copy engine may still be reading it when this call returns
+        if not hasattr(self, "_async_inputs"):
+            self._async_inputs = {}
+        self._async_inputs[int(slot)] = cur
         return ResidentPlanes(self, h)
 
     def wait(self, slot):
         mv = np.empty((self.N, 2), np.int16)
         ns = ctypes.c_uint32(0)
-        self._ck(self._lib.vcs_wait(self._h, int(slot), mv.ctypes.data_as(_i16p), ctypes.byref(ns)))
+        try:
+            self._ck(self._lib.vcs_wait(self._h, int(slot), mv.ctypes.data_as(_i16p), ctypes.byref(ns)))
+        finally:
+            getattr(self, "_async_inputs", {}).pop(int(slot), None)
         return mv, ns.value
 
     # -- intra prediction (next row N1) ---------------------------------------
@@ -795,17 +804,36 @@ def rendezvous_unique_id(rank, world, timeout_s=180.0, tag=None, make_id=None):
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
     path = os.path.join(base, "vcs_hip_rccl_id_%d_%s_w%d" % (os.getuid(), tag, world))
     if rank == 0:
+        try:
+            os.unlink(path)            # whatever an earlier (crashed) launch with this tag left behind
+        except OSError:
+            pass
         uid = make_id()
         tmp = path + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as f:
             f.write(b"VCSID1" + uid)
         os.replace(tmp, path)
+
+        # The other ranks only take a file touched after their own start (below); a rank the launcher
+        # starts late must still find this one fresh, so it is touched for a while from a thread
+        # (rank 0 itself is about to block in ncclCommInitRank).  A file nobody touches any more --
+        # one left by a crashed launch -- is never accepted.
+        def keep_fresh():
+            t_end = time.time() + min(timeout_s, 30.0)
+            while time.time() < t_end:
+                try:
+                    os.utime(path, None)
+                except OSError:
+                    return             # rendezvous_cleanup removed it: everybody has joined
+                time.sleep(0.1)
+        import threading
+        threading.Thread(target=keep_fresh, daemon=True).start()
         return uid
     t0 = time.time()
     while time.time() - t0 < timeout_s:
         try:
             st = os.stat(path)
-            if time.time() - st.st_mtime < timeout_s:
+            if st.st_mtime >= _T_START - 0.5 and time.time() - st.st_mtime < 5.0:
                 blob = open(path, "rb").read()
                 if len(blob) == 6 + 128 and blob[:6] == b"VCSID1":
                     return blob[6:]
