@@ -21,6 +21,7 @@ ap.add_argument("--H", type=int, default=1080)
 ap.add_argument("--W", type=int, default=1920)
 ap.add_argument("--static", type=float, default=0.0, help="fraction of the picture (left part) copied from the reference")
 ap.add_argument("--label", default="")
+ap.add_argument("--no-events", action="store_true", help="wall time only: no timing events on the kernels")
 a = ap.parse_args()
 
 H, W, n = a.H, a.W, a.frames
@@ -46,7 +47,7 @@ with vcs_hip.Context(H, W, 16, 8) as c:
         if k % 16 == 0:
             c.sync()
     c.sync()
-    c.timing_enable(True)
+    c.timing_enable(not a.no_events)
     c.timing_reset()
     t0 = time.perf_counter()
     for k in range(a.steps):

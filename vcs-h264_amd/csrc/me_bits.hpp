@@ -479,38 +479,34 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
         }
 
         // ---- arg-min per frame (motion.py:149: strict <, raster order = lowest index on ties) -----
-        uint32_t my_mv = 0, my_clo = 0, my_chi = 0;
+        // the winning key of frame f goes to lane f, which decodes and stores its frame's result
+        uint32_t my_key = 0xFFFFFFFFu;
 #pragma unroll
         for (int f = 0; f < NF; f++) {
-            if (f < nf) {
-                const uint2 bi = binfo[(size_t)(f0 + f) * g.N + blk];
-                uint32_t mvw = 0u;
-                unsigned long long cw = bi.x;          // static block: [0, 0], cost = the difference
-                const bool is_static = (skip >> f) & 1u;
-                if (!is_static) {
-                    const uint32_t key = wave_min_u32(best[f]);
-                    int bx = 0, byy = 0;
-                    cw = 9999999999ull;                // motion.py:120: no candidate
-                    if (key != 0xFFFFFFFFu) {
-                        const int cb = (int)(key & 127u);
-                        const int cbi = (int)(((uint32_t)cb * inv_ncj) >> 16);
-                        byy = i_min + cbi * STEP;
-                        bx = j_min + (cb - cbi * ncj) * STEP;
-                        cw = (key >> 7) - bi.y;
-                    }
-                    mvw = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);  // [dx, dy]
-                }
-                if (lane == f) {
-                    my_mv = mvw;
-                    my_clo = (uint32_t)cw;
-                    my_chi = (uint32_t)(cw >> 32);
-                }
+            if (!((skip >> f) & 1u)) {   // scalar
+                const uint32_t key = wave_min_u32(best[f]);
+                if (lane == f) my_key = key;
             }
         }
         if (lane < nf) {
             const size_t o = (size_t)(f0 + lane) * g.N + blk;
-            *(uint32_t *)(mv + 2 * o) = my_mv;
-            if (cost_out) cost_out[o] = (unsigned long long)my_clo | ((unsigned long long)my_chi << 32);
+            const uint2 bi = binfo[o];
+            uint32_t mvw = 0u;
+            unsigned long long cw = bi.x;              // static block: [0, 0], cost = the difference
+            if (!((skip >> lane) & 1u)) {
+                int bx = 0, byy = 0;
+                cw = 9999999999ull;                    // motion.py:120: no candidate
+                if (my_key != 0xFFFFFFFFu) {
+                    const int cb = (int)(my_key & 127u);
+                    const int cbi = (int)(((uint32_t)cb * inv_ncj) >> 16);
+                    byy = i_min + cbi * STEP;
+                    bx = j_min + (cb - cbi * ncj) * STEP;
+                    cw = (my_key >> 7) - bi.y;
+                }
+                mvw = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);  // [dx, dy]
+            }
+            *(uint32_t *)(mv + 2 * o) = mvw;
+            if (cost_out) cost_out[o] = cw;
         }
     }
     if (clk_out && threadIdx.x == 0) {
