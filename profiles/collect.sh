@@ -7,7 +7,7 @@
 #      pass, the TCC block holds four counters; never combined with sys/hip/hsa tracing)
 # Afterwards, here: cp gpurun_out/profiles_<tag>/{pmc_per_dispatch.json,kernel_stats.csv} profiles/<tag>/
 # and python profiles/make_traffic.py profiles/<tag>/pmc_per_dispatch.json -> profiles/hbm_traffic.json
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/profiles_$tag
 mkdir -p $out
@@ -41,4 +41,4 @@ json.dump(summary, open(out + '/pmc_per_dispatch.json', 'w'), indent=1, sort_key
 print(json.dumps(summary, indent=1, sort_keys=True))
 PY
 cat $out/kernel_stats.csv
-tail -1 $out/stats.log > $out/bench_line_under_rocprof.json; cat $out/bench_line_under_rocprof.json
+grep "^{\"metric\"" $out/stats.log | tail -1 > $out/bench_line_under_rocprof.json; cat $out/bench_line_under_rocprof.json

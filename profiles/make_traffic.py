@@ -13,13 +13,16 @@ import sys
 H, W, FRAMES, BS = 1080, 1920, 29, 16
 F = H * W * 3
 N = (H // BS) * (W // BS)
+TABLE = H * (W // BS) * 960   # k_bits_ref's chunk table: 960 B per (picture row, block column)
 ALG = {  # algorithmic bytes per launch (29 P frames)
-    "k_me16g": FRAMES * (2 * F + 4 * N),
+    "k_me16b": FRAMES * (2 * F + 4 * N),          # the search STAGE's bytes (k_bits_cur runs in front of it)
+    "k_bits_cur": FRAMES * (2 * F + 8 * N),       # frames in, as many bytes of bit planes + a record per block out
+    "k_bits_ref": F + TABLE,                      # one reference frame in, the chunk table out
     "k_fdct<residual>": FRAMES * (10 * F + 4 * N),
     "k_me16_sums": F + N * 128 * 4,
 }
-PMC_PREFIX = {"vcs::k_me16g": "k_me16g", "vcs::k_fdct<1, 0,": "k_fdct<residual>",
-              "vcs::k_me16_sums": "k_me16_sums"}   # kernel-name prefixes in the PMC summary
+PMC_PREFIX = {"vcs::k_me16b": "k_me16b", "vcs::k_bits_cur": "k_bits_cur", "vcs::k_bits_ref": "k_bits_ref",
+              "vcs::k_fdct<1, 0,": "k_fdct<residual>", "vcs::k_me16_sums": "k_me16_sums"}   # kernel-name prefixes in the PMC summary
 
 
 def main(path):
@@ -30,7 +33,7 @@ def main(path):
         if len(keys) != 1:
             sys.exit("expected one kernel starting with %r, found %r" % (prefix, keys))
         v = pmc[keys[0]]
-        if name == "k_me16g":
+        if name == "k_me16b":
             sampled = int(v["dispatches_sampled"])
         fetch, write = int(v["FETCH_SIZE"] * 1024), int(v["WRITE_SIZE"] * 1024)
         corrected = 2 * fetch + write
@@ -47,23 +50,22 @@ def main(path):
     out = {
         "workload": {"H": H, "W": W, "frames_per_launch": FRAMES, "me_bs": BS},
         "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of "
-               "`bench.py --steps 10 --warmup 2` (profiles/collect.sh; the bench rotates through three resident copies of the GOP, "
-               "so nothing is re-read from the Infinity Cache); KB per dispatch averaged over "
-               "%d dispatches.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B "
-               "per 128-B request for wide coalesced reads, so it is doubled; WRITE_SIZE is exact "
-               "(k_fdct: 29 x 3 x 1080 x 1920 x 8 B = 1,443,225,600 B).  Calibration in our own access "
-               "pattern: k_me16_sums reads one 6.22 MB reference frame through 16-byte unaligned "
-               "window loads; a raw FETCH_SIZE below the 6.22 MB it must read at least once shows that the "
-               "under-count applies to this pattern too.  k_fdct's 4-byte-per-lane "
-               "pixel loads are uncalibrated: its read figure is an upper bound.  k_fdct's traffic is "
-               "below its algorithmic bytes because the latter charge the reference frame once per P "
-               "frame (SURVEY 8d) while neighbouring strips share it in L2.  k_me16g's WRITE_SIZE "
-               "is mostly its scratch backing store (12 spilled registers of the 128-VGPR build: 48 B x 64 "
-               "lanes x 4,096 waves = 12.6 MB, written once per wave in the unit prologue), not results: "
-               "the vectors are 0.93 MB per launch; its FETCH_SIZE includes the 180 MB of frames it streams "
-               "once more, as full lines, for the tail kernel (the in-kernel Infinity Cache prefetch), which "
-               "is why its traffic is now above its algorithmic bytes.  The strips of k_fdct are dealt in "
-               "raster order; its reads of those frames are served by the Infinity Cache (FETCH_SIZE counts them)."
+               "`bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras` (profiles/collect.sh; the bench rotates "
+               "through three resident copies of the GOP, so nothing is re-read from the Infinity Cache); KB per "
+               "dispatch averaged over %d dispatches.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
+               "counts 64 B per 128-B request for wide coalesced reads, so it is doubled; WRITE_SIZE is exact "
+               "(k_fdct: 29 x 3 x 1080 x 1920 x 8 B = 1,443,225,600 B; k_bits_cur: 29 x 8,040 x 776 B = 180.9 MB; "
+               "k_bits_ref: 1080 x 120 x 960 B = 124.4 MB).  The motion-search stage is k_bits_cur (frames -> bit "
+               "planes, static test) + k_me16b (the search): the stage's algorithmic bytes (2F + 4N per frame) are "
+               "listed under k_me16b; its real traffic is the sum of the two kernels -- the frames once (k_bits_cur), "
+               "the planes written and read back twice (LDS-direct loads and scalar loads, the second from L2), the "
+               "124 MB chunk table of the reference, and the 180 MB of frames the launch's last workgroups stream once "
+               "more, as full lines, for the tail kernel (the Infinity Cache prefetch) -- which is why it is far above "
+               "the algorithmic figure: the stage buys a 2.2 x shorter search with memory traffic the vector-issue-bound "
+               "kernel has room for.  k_fdct's 4-byte-per-lane pixel loads are uncalibrated: its read figure is an "
+               "upper bound; its traffic is below its algorithmic bytes because the latter charge the reference frame "
+               "once per P frame (SURVEY 8d) while neighbouring strips share it in L2; its reads of the frames are "
+               "served by the Infinity Cache (FETCH_SIZE counts them)."
                % sampled,
         "source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)) + "/.."),
         "kernels": kernels,
