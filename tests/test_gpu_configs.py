@@ -128,6 +128,31 @@ def test_config4_4k_per_rank_gop_share(vh, oracle):
             assert np.array_equal(c.gop_get_decoded(k), oracle.decode_p(omv, oplanes, ref, 16)), k
 
 
+def test_config4_4k_two_gpu_share_banded_bitplane_search(vh, oracle):
+    """C4 on two GPUs: 15 of the 29 P frames of a 3840x2160 GOP on rank 0 -- enough frames for the
+    bit-plane search, whose chunk table goes in four bands of 60 block columns at this width, while
+    the tail runs in cache-sized sub-batches; vectors of every frame, planes of three, vs the oracle."""
+    from gop import shard_frames
+    from synth import synth_gop
+    H, W = 2160, 3840
+    first, count = shard_frames(29, 2, 0)
+    assert (first, count) == (0, 15)
+    ref, frames = synth_gop(H, W, count, seed=99, first=1 + first)
+    frames[5][:, : W // 3] = ref[:, : W // 3]          # a static region
+    with vh.Context(H, W, 16) as c:
+        c.set_ref(ref)
+        c.gop_reserve(count)
+        c.gop_upload(0, frames)
+        c.gop_encode(0, count)
+        mv, ns = c.gop_get_mv(0, count)
+        for k in range(count):
+            omv, ons = oracle.me(frames[k], ref, 16)
+            assert np.array_equal(mv[k], omv) and ns[k] == ons, k
+        for k in (0, 7, 14):
+            _, oplanes, _ = oracle.encode_p(frames[k], ref, 16)
+            assert np.array_equal(c.gop_get_planes(k).view(np.int64), oplanes.view(np.int64)), k
+
+
 # ------------------------------------------------------------ ADVICE (round 1) ----
 def test_similarity_threshold_survives_q_pushes(vh, oracle, capsys):
     """motion.SIMILARITY_THRESHOLD edited by hand (as the reference expects) must

@@ -737,6 +737,8 @@ def test_forced_kernel_variants_subprocess():
     # frames and ragged sizes included; BITS=0: never (the kernels below it run GOP-sized batches too)
     for env_add, k in (({"VCS_ME16_BITS": "2"}, sel + " or gop_matches_single or bitplane"),
                        ({"VCS_ME16_BITS": "2", "VCS_BITS_PF": "0"}, "gop_1080p_vs_oracle or gop_matches_single"),
+                       # the chunk table in many narrow bands of block columns (what 4K does with four)
+                       ({"VCS_ME16_BITS": "2", "VCS_BITS_BAND_KB": "1024"}, "bitplane or golden_me_small or gop_1080p_vs_oracle"),
                        ({"VCS_ME16_BITS": "2", "VCS_L3_PREFETCH": "0"}, "gop_1080p_vs_oracle or gop_matches_single"),
                        ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2"}, sel),
                        ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "0", "VCS_ME8_GROUP": "0"}, sel),

@@ -68,17 +68,19 @@ __device__ __forceinline__ void bits_transpose8(uint32_t (&x)[8]) {
 }
 
 // ---- reference chunks ---------------------------------------------------------------------
-// rtab[((w * nbx + a) * 6 + q) * 40 + m * 4 + e] = plane dword t = 4 q + e of the 96-byte string
+// rtab[((w * na + (a - a0)) * 6 + q) * 40 + m * 4 + e] = plane dword t = 4 q + e of the 96-byte string
 // (row w, bytes 3 j .. 3 j + 47) ++ (row w + 1, same bytes), j = max(16 a - 32, 0) + 5 m: the
 // m-th candidate column of block column a (motion.py:125-140).  Every w: a candidate's rows
 // start at i_min + 5 ci, of either parity.  One thread per (w, a, m).
+// The table covers a BAND of block columns [a0, a0 + na) (the whole picture when it fits the
+// Infinity Cache beside the planes; 4K goes in four bands): rtab's block-column index is a - a0.
 __global__ __launch_bounds__(256) void k_bits_ref(const uint8_t *__restrict__ ref, uint32_t ref_bytes, Geom g,
-                                                  uint32_t *__restrict__ rtab) {
-    const uint32_t total = (uint32_t)g.H * (uint32_t)g.nbx * kBitsM;
+                                                  uint32_t *__restrict__ rtab, int a0, int na) {
+    const uint32_t total = (uint32_t)g.H * (uint32_t)na * kBitsM;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= total) return;
     const uint32_t m = idx % kBitsM, wa = idx / kBitsM;
-    const uint32_t a = wa % (uint32_t)g.nbx, w = wa / (uint32_t)g.nbx;
+    const uint32_t a = (uint32_t)a0 + wa % (uint32_t)na, w = wa / (uint32_t)na;
     const int j = max(16 * (int)a - 32, 0) + 5 * (int)m;
     const __amdgpu_buffer_rsrc_t r_ref = buf_rsrc(ref, ref_bytes);   // reads past the slack rows return 0
     const uint32_t off = w * (uint32_t)g.pitch + 3u * (uint32_t)j;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                                                const uint8_t *__restrict__ pf_base, uint32_t pf_total16,
                                                int n_search_wgs, int pf_octets, int pf_ratio,
                                                const uint32_t *__restrict__ ns_part, int ns_per_frame,
-                                               uint32_t *__restrict__ n_static) {
+                                               uint32_t *__restrict__ n_static, int a0, int na) {
     constexpr int BS = 16, WIN = 32, STEP = 5;
     using L = BitsLds<NF>;
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[4 * L::kWave];
@@ -303,9 +305,9 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
     // column the chunk rows of vertically adjacent blocks overlap: they meet in the XCD's L2), dealt
     // to the 8 XCDs in contiguous ranges; a workgroup = 4 consecutive units (the 4 frame groups of
     // one block position when ngroups = 4: they read the same chunks through one L1)
-    const int total = g.N * ngroups;
+    const int total = na * g.nby * ngroups;   // the band's block positions x frame groups
     const int chunk = ((total + 7) / 8 + 3) & ~3;
-    if (blockIdx.x == 0) {   // static blocks per frame: the sums of k_bits_cur's per-workgroup counts
+    if (blockIdx.x == 0 && a0 == 0) {   // static blocks per frame: the sums of k_bits_cur's per-workgroup counts
         for (int f = wave; f < n_frames; f += 4) {
             uint32_t v = 0;
             for (int i = lane; i < ns_per_frame; i += 64) v += ns_part[(size_t)f * ns_per_frame + i];
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
     const int u = xcd * chunk + ul;
     if (ul < chunk && u < total) {
         const int pos = u / ngroups, grp = u - pos * ngroups;
-        const int bxi = pos / g.nby, byi = pos - bxi * g.nby;
+        const int bl = pos / g.nby, byi = pos - bl * g.nby, bxi = a0 + bl;   // bl: column inside the band
         const int blk = byi * g.nbx + bxi;
         int f0, nf;
         bits_group(n_frames, ngroups, grp, f0, nf);
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
 #pragma unroll
         for (int f = 0; f < NF; f++) best[f] = 0xFFFFFFFFu;
 
-        const size_t wstride = (size_t)g.nbx * kBitsWA;   // dwords per window row of rtab
+        const size_t wstride = (size_t)na * kBitsWA;      // dwords per window row of rtab
         const uint32_t *__restrict__ cblk = cpl + ((size_t)f0 * g.N + blk) * kBitsBlk;
         const size_t cfs = (size_t)g.N * kBitsBlk;         // dwords per frame of cpl
 
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                 const int ci = (int)(((uint32_t)cc * inv_ncj) >> 16), cj = cc - ci * ncj;
                 const uint32_t sr = sums[(size_t)blk * kMe16SumStride + cc];
                 const uint32_t *__restrict__ rp =
-                    rtab + (size_t)(i_min + STEP * ci) * wstride + (size_t)bxi * kBitsWA + cj * 4;
+                    rtab + (size_t)(i_min + STEP * ci) * wstride + (size_t)bl * kBitsWA + cj * 4;
                 uint32_t acc[NF];
 #pragma unroll
                 for (int f = 0; f < NF; f++) acc[f] = 0;
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                     const int cand = 64 + ck;
                     const int ci = (int)(((uint32_t)cand * inv_ncj) >> 16), cj = cand - ci * ncj;
                     uint32_t r[kBitsT];
-                    bits_ld_chunk(r, rtab + (size_t)(i_min + STEP * ci + 2 * p) * wstride + (size_t)bxi * kBitsWA + cj * 4);
+                    bits_ld_chunk(r, rtab + (size_t)(i_min + STEP * ci + 2 * p) * wstride + (size_t)bl * kBitsWA + cj * 4);
                     const uint4 *cq = (const uint4 *)(s_c + p * (NF * 96));
 #pragma unroll
                     for (int f = 0; f < NF; f++) {
@@ -521,7 +523,25 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
 #endif
 constexpr int kBitsNF = VCS_BITS_NF;   // frames per wave the search kernel is unrolled for
 
-inline size_t me_bits_rtab_bytes(const Geom &g) { return (size_t)g.H * g.nbx * kBitsWA * 4 + 256; }
+// Bands of block columns: the chunk table of one band stays below kBitsBandBytes (it has to live in
+// the 256 MB Infinity Cache beside the planes the search streams: 124 MB for all of 1080p, 4 x 124 MB
+// for 4K).
+constexpr size_t kBitsBandBytes = (size_t)160 << 20;
+inline size_t me_bits_band_bytes() {   // VCS_BITS_BAND_KB: tests force many narrow bands on small frames
+    static const size_t v = [] {
+        const char *e = getenv("VCS_BITS_BAND_KB");
+        const long long kb = e ? atoll(e) : 0;
+        return kb > 0 ? (size_t)kb << 10 : kBitsBandBytes;
+    }();
+    return v;
+}
+inline int me_bits_bands(const Geom &g) {
+    const size_t per_col = (size_t)g.H * kBitsWA * 4;
+    const int max_cols = (int)(me_bits_band_bytes() / per_col) > 0 ? (int)(me_bits_band_bytes() / per_col) : 1;
+    return (g.nbx + max_cols - 1) / max_cols;
+}
+inline int me_bits_band_cols(const Geom &g) { const int nb = me_bits_bands(g); return (g.nbx + nb - 1) / nb; }
+inline size_t me_bits_rtab_bytes(const Geom &g) { return (size_t)g.H * me_bits_band_cols(g) * kBitsWA * 4 + 256; }
 inline size_t me_bits_cpl_bytes(const Geom &g, int n) { return (size_t)n * g.N * kBitsBlk * 4; }
 inline size_t me_bits_binfo_bytes(const Geom &g, int n) {   // {static-test sum, sum(c)} per block + the static counts per workgroup
     return (size_t)n * g.N * sizeof(uint2) + (size_t)n * (8 * (((g.N + 31) / 32 + 7) / 8)) * sizeof(uint32_t);
@@ -537,24 +557,26 @@ inline int me_bits_mode() {
     }();
     return v;
 }
-// Measured on MI355X (tools/gpu_bits_sizes.sh, whole step incl. k_bits_cur and the tables): 1080p,
-// n = 4: 0.212 vs 0.196 ms with k_me16g; n = 8: 0.290 vs 0.344; n = 29: 0.71 vs 0.87.  The chunk
-// table is 115 KB per picture row: 124 MB at 1080p; at 4K (497 MB, more than the Infinity Cache
-// holds) the search re-reads it from HBM per sub-batch and the step loses (3.8 vs 3.6 ms), so
-// frames that wide stay on k_me16g until the table is built per band of block columns.
+// Measured on MI355X (whole step incl. k_bits_cur and the tables): 1080p (one band,
+// tools/gpu_bits_sizes.sh), n = 4: 0.212 vs 0.196 ms with k_me16g; n = 8: 0.290 vs 0.344; n = 29: 0.67
+// vs 0.87.  4K (four bands of 60 block columns, the table rebuilt band by band in every launch,
+// tools/gpu_4k_ab.sh): n = 8: 1.22 vs 0.96 ms; n = 12: 1.48 vs 1.49; n = 15: 1.79 vs 1.85; n = 20: 2.15
+// vs 2.40; n = 29: 2.86 vs 3.54.  (One 497 MB table for all of 4K, re-read from HBM by every
+// sub-batch: 3.8 ms -- why there are bands.)
 constexpr int kBitsMinFrames = 6;
-constexpr size_t kBitsMaxTable = (size_t)192 << 20;
 inline bool me_bits_worthwhile(const Geom &g, int n) {
     const int m = me_bits_mode();
     if (m == 0 || !me_fast_supported(g)) return false;
     if ((long long)g.N * n * kBitsBlk > 0x7FFFFFFFll * 4) return false;
-    return m == 2 || (n >= kBitsMinFrames && me_bits_rtab_bytes(g) <= kBitsMaxTable);
+    return m == 2 || n >= kBitsMinFrames + 3 * (me_bits_bands(g) - 1);
 }
 inline int me_bits_groups(int n) { return (n + kBitsNF - 1) / kBitsNF; }
 
-inline void launch_bits_ref(const Geom &g, hipStream_t stream, const uint8_t *ref, size_t ref_bytes, uint32_t *rtab) {
-    const uint32_t total = (uint32_t)g.H * (uint32_t)g.nbx * kBitsM;
-    hipLaunchKernelGGL(k_bits_ref, dim3((total + 255) / 256), dim3(256), 0, stream, ref, (uint32_t)ref_bytes, g, rtab);
+inline void launch_bits_ref(const Geom &g, hipStream_t stream, const uint8_t *ref, size_t ref_bytes, uint32_t *rtab,
+                            int a0, int na) {
+    const uint32_t total = (uint32_t)g.H * (uint32_t)na * kBitsM;
+    hipLaunchKernelGGL(k_bits_ref, dim3((total + 255) / 256), dim3(256), 0, stream, ref, (uint32_t)ref_bytes, g, rtab,
+                       a0, na);
 }
 inline int me_bits_cur_wgs(const Geom &g) {   // workgroups of k_bits_cur per frame (a multiple of 8)
     return 8 * (((g.N + kBitsCurBlocks - 1) / kBitsCurBlocks + 7) / 8);
@@ -567,10 +589,11 @@ inline void launch_bits_cur(const Geom &g, hipStream_t stream, const uint8_t *cu
 }
 inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t *rtab, const uint32_t *cpl,
                                const uint2 *binfo, const uint32_t *sums, int n, int16_t *mv, const uint32_t *ns_part,
-                               uint32_t *ns, unsigned long long *cost, unsigned long long *clk, const uint8_t *pf_base = nullptr,
-                               size_t pf_bytes = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+                               uint32_t *ns, unsigned long long *cost, unsigned long long *clk, int a0, int na,
+                               const uint8_t *pf_base = nullptr, size_t pf_bytes = 0, hipEvent_t ev_start = nullptr,
+                               hipEvent_t ev_stop = nullptr) {
     const int ngroups = me_bits_groups(n);
-    const int total = g.N * ngroups;
+    const int total = na * g.nby * ngroups;
     const int chunk = ((total + 7) / 8 + 3) & ~3;
     const int nsearch = 8 * (chunk / 4);
     // prefetch workgroups: octets interleaved 1 : ratio with the last search octets (VCS_BITS_PF_WGS, VCS_BITS_PF_RATIO)
@@ -585,7 +608,8 @@ inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t
     if (pf8 == 0) pf_base = nullptr;
     hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(nsearch + 8 * pf8), dim3(256), 0, stream, ev_start, ev_stop, 0,
                           rtab, cpl, binfo, sums, g, n, ngroups, mv, cost, clk, pf_base,
-                          (uint32_t)(pf_base ? pf_bytes >> 4 : 0), nsearch, pf8, ratio, ns_part, me_bits_cur_wgs(g), ns);
+                          (uint32_t)(pf_base ? pf_bytes >> 4 : 0), nsearch, pf8, ratio, ns_part, me_bits_cur_wgs(g), ns,
+                          a0, na);
 }
 
 }  // namespace vcs

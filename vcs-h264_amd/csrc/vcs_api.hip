@@ -286,19 +286,14 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     if (bits) {
         int rc = ensure_bits(c, n);
         if (rc) return rc;
-        if (!c->rtab_valid) {   // once per reference frame, like the sum table
-            launch_bits_ref(c->g, c->stream, ref, c->Fs + me_fast_ref_slack(c->g), c->d_rtab);
-            HIP_TRY(c, hipGetLastError());
-            c->rtab_valid = true;
-        }
-        EvPair evp, ev;
+        const int nb = me_bits_bands(c->g), bc = me_bits_band_cols(c->g);
+        EvPair evp;
         if ((rc = t_begin(c, VCS_T_ME_PREP, &evp, /*attach=*/true))) return rc;
         uint32_t *ns_part = (uint32_t *)(c->d_binfo + (size_t)n * c->g.N);   // behind the n * N block records
         launch_bits_cur(c->g, c->stream, curs, stride, ref, n, c->d_cpl, c->d_binfo, ns_part, evp.a, evp.b);
         if ((rc = t_end(c, &evp))) return rc;
-        if ((rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/true))) return rc;
         // The caller's Infinity Cache prefetch of the frames (vcs_gop_encode) rides at the END of the
-        // search launch (prefetch workgroups dispatched behind the search's own, me_bits.hpp).
+        // (last) search launch (prefetch workgroups dispatched behind the search's own, me_bits.hpp).
         // Measured alternatives, 29 x 1080p: k_bits_cur's own reads of the frames are gone from the
         // cache when the tail starts (tail 0.37 instead of 0.29 ms: the search moves 300 MB of planes
         // and chunks in between); so is a k_l3_prefetch started beside the search on a second stream;
@@ -306,10 +301,28 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         // a separate pass between search and tail: its own 0.04 ms.
         static const bool pf_tail_wgs = [] { const char *e = getenv("VCS_BITS_PF"); return !(e && e[0] == '0'); }();
         const bool pf = c->pf_in_search && pf_tail_wgs && (size_t)n * stride < 0xFFFFFFFFull;
-        launch_bits_search(c->g, c->stream, c->d_rtab, c->d_cpl, c->d_binfo, c->d_sums, n, mv, ns_part, ns, cost,
-                           c->timing ? c->d_clk : nullptr, pf ? curs : nullptr, (size_t)n * stride, ev.a, ev.b);
         c->pf_in_search = pf;
-        return t_end(c, &ev);
+        // The chunk table covers one band of block columns (the whole picture at 1080p, a quarter of
+        // it at 4K): with one band it is built once per reference frame, like the sum table; with
+        // several it is rebuilt band by band in every launch (25 us per band).
+        const bool nc = c->t_no_count;
+        for (int band = 0; band < nb && !rc; band++) {
+            const int a0 = band * bc, na = std::min(bc, c->g.nbx - a0);
+            if (nb > 1 || !c->rtab_valid) {
+                launch_bits_ref(c->g, c->stream, ref, c->Fs + me_fast_ref_slack(c->g), c->d_rtab, a0, na);
+                HIP_TRY(c, hipGetLastError());
+            }
+            EvPair ev;
+            c->t_no_count = nc || band > 0;   // timing: one "launch" per call, however many bands
+            if ((rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/true))) break;
+            launch_bits_search(c->g, c->stream, c->d_rtab, c->d_cpl, c->d_binfo, c->d_sums, n, mv, ns_part, ns, cost,
+                               c->timing ? c->d_clk : nullptr, a0, na, pf && band == nb - 1 ? curs : nullptr,
+                               (size_t)n * stride, ev.a, ev.b);
+            rc = t_end(c, &ev);
+        }
+        c->t_no_count = nc;
+        c->rtab_valid = nb == 1;
+        return rc;
     }
     const bool fast16 = c->me_fast_ok && !force_generic;
     const bool group8 = c->me_fast8_ok && !force_generic && me8g_worthwhile(c->g, c->cus, n);
@@ -1218,16 +1231,27 @@ int vcs_gop_encode(vcs_ctx *c, int first, int n) {
         if (chunk < 2) chunk = (size_t)n;             // frames too large to hold two: one batch, no prefetch
     }
     const bool pf_on = pf && chunk * c->Fs <= l3_prefetch_max_bytes();
+    // The bit-plane search wants the whole batch (its per-launch tables are repaid by many frames):
+    // when it takes it, only the tail goes in cache-sized sub-batches (with the separate prefetch pass)
+    const bool whole_me = chunk < (size_t)n && c->me_fast_ok && me_bits_worthwhile(c->g, n);
+    if (whole_me) {
+        c->pf_in_search = false;
+        if ((rc = launch_me(c, c->d_ref, curs, c->Fs, n, mv, c->g_ns + first, nullptr))) return rc;
+        if (c->ev_me_done) {   // the group's collectives start behind the search, beside the tail
+            HIP_TRY(c, hipEventRecord(c->ev_me_done, c->stream));
+            c->me_done_rec = true;
+        }
+    }
     for (size_t f0 = 0; f0 < (size_t)n; f0 += chunk) {
         const int m = (int)std::min(chunk, (size_t)n - f0);
         const uint8_t *cc = curs + f0 * c->Fs;
         int16_t *mvc = mv + f0 * N * 2;
         c->t_no_count = f0 > 0;                      // timing: one "launch" per call, whatever the batching
-        c->pf_in_search = pf_on && m >= 2 && l3_prefetch_in_search();
-        rc = launch_me(c, c->d_ref, cc, c->Fs, m, mvc, c->g_ns + first + f0, nullptr);
+        c->pf_in_search = !whole_me && pf_on && m >= 2 && l3_prefetch_in_search();
+        rc = whole_me ? VCS_OK : launch_me(c, c->d_ref, cc, c->Fs, m, mvc, c->g_ns + first + f0, nullptr);
         const bool pf_done = c->pf_in_search;
         c->pf_in_search = false;
-        if (!rc && f0 + m == (size_t)n && c->ev_me_done) {  // the group's collectives start behind the search, beside the tail
+        if (!rc && !whole_me && f0 + m == (size_t)n && c->ev_me_done) {  // the group's collectives start behind the search, beside the tail
             if (hipEventRecord(c->ev_me_done, c->stream) != hipSuccess) rc = fail(c, VCS_E_HIP, "hipEventRecord failed");
             c->me_done_rec = true;
         }
