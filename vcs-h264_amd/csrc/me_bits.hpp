@@ -523,10 +523,12 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
 #endif
 constexpr int kBitsNF = VCS_BITS_NF;   // frames per wave the search kernel is unrolled for
 
-// Bands of block columns: the chunk table of one band stays below kBitsBandBytes (it has to live in
-// the 256 MB Infinity Cache beside the planes the search streams: 124 MB for all of 1080p, 4 x 124 MB
-// for 4K).
-constexpr size_t kBitsBandBytes = (size_t)160 << 20;
+// Bands of block columns: the chunk table of one band stays below kBitsBandBytes -- 1 GiB, so 1080p
+// (124 MB) and 4K (497 MB) are one band; measured at 4K, four 124 MB bands are slower than the one
+// table (2.86 vs 2.75 ms per 29 frames: the column-major unit order already keeps a chunk's reuse
+// inside one XCD's L2, the bands only add launches).  The machinery is for frames whose table would
+// not fit a sensible allocation, and for tests (VCS_BITS_BAND_KB).
+constexpr size_t kBitsBandBytes = (size_t)1 << 30;
 inline size_t me_bits_band_bytes() {   // VCS_BITS_BAND_KB: tests force many narrow bands on small frames
     static const size_t v = [] {
         const char *e = getenv("VCS_BITS_BAND_KB");
@@ -557,18 +559,20 @@ inline int me_bits_mode() {
     }();
     return v;
 }
-// Measured on MI355X (whole step incl. k_bits_cur and the tables): 1080p (one band,
-// tools/gpu_bits_sizes.sh), n = 4: 0.212 vs 0.196 ms with k_me16g; n = 8: 0.290 vs 0.344; n = 29: 0.67
-// vs 0.87.  4K (four bands of 60 block columns, the table rebuilt band by band in every launch,
-// tools/gpu_4k_ab.sh): n = 8: 1.22 vs 0.96 ms; n = 12: 1.48 vs 1.49; n = 15: 1.79 vs 1.85; n = 20: 2.15
-// vs 2.40; n = 29: 2.86 vs 3.54.  (One 497 MB table for all of 4K, re-read from HBM by every
-// sub-batch: 3.8 ms -- why there are bands.)
-constexpr int kBitsMinFrames = 6;
+// Measured on MI355X (whole step incl. k_bits_cur and the tables), bit-plane search vs k_me16g:
+// 1080p (tools/gpu_bits_sizes.sh), n = 4: 0.212 vs 0.196 ms; n = 8: 0.290 vs 0.344; n = 29: 0.67 vs 0.87.
+// 4K (tools/gpu_4k_ab.sh; one 497 MB table, the search over the whole batch, the tail in cache-sized
+// sub-batches), n = 6: 0.92 vs 0.87 ms; n = 8: 1.13 vs 0.96; n = 12: 1.38 vs 1.47; n = 15: 1.59 vs
+// 1.82; n = 29: 2.75 vs 3.55.  (The table in four bands of 60 block columns, each rebuilt per launch:
+// n = 29 2.86 ms -- more launches, nothing gained from the smaller table; with the SEARCH in sub-batches
+// of 8 frames, each re-reading the table: 3.8 ms.)
+constexpr int kBitsMinFrames = 6, kBitsMinFramesBig = 10;
 inline bool me_bits_worthwhile(const Geom &g, int n) {
     const int m = me_bits_mode();
     if (m == 0 || !me_fast_supported(g)) return false;
     if ((long long)g.N * n * kBitsBlk > 0x7FFFFFFFll * 4) return false;
-    return m == 2 || n >= kBitsMinFrames + 3 * (me_bits_bands(g) - 1);
+    const int need = (g.N > 16384 ? kBitsMinFramesBig : kBitsMinFrames) + 3 * (me_bits_bands(g) - 1);
+    return m == 2 || n >= need;
 }
 inline int me_bits_groups(int n) { return (n + kBitsNF - 1) / kBitsNF; }
 
