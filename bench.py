@@ -626,8 +626,8 @@ def main():
         # vectors; the tail reads cur + ref + vectors, writes 3 f64 planes
         per_mb = {vcs_hip.T_ME: (2 * F + 4 * N) / N, vcs_hip.T_ENC_TAIL: (10 * F + 4 * N) / N}
         bits = launches[vcs_hip.T_ME_PREP] > 0     # the bit-plane search ran (k_bits_cur + k_me16b)
-        me_name = ("k_me16b" if bits else "k_me16g" if bs == 16 and n0 >= 4 else "k_me16r/k_me16" if bs == 16
-                   else "k_me8" if bs == 8 else "k_me_generic")
+        me_name = (("k_me16b" if bs == 16 else "k_me8b") if bits else "k_me16g" if bs == 16 and n0 >= 4
+                   else "k_me16r/k_me16" if bs == 16 else "k_me8" if bs == 8 else "k_me_generic")
         names = {vcs_hip.T_ME: me_name, vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
         tj = {}
         traffic = {}
@@ -652,7 +652,7 @@ def main():
                 # (current blocks -> bit planes, static test) runs in front of k_me16b
                 st_ms = (ms[vcs_hip.T_ME] + ms[vcs_hip.T_ME_PREP]) / max(1, int(launches[slot]))
                 st = alg / (st_ms * 1e-3) / 1e9
-                r["stage"] = {"kernels": "k_bits_cur + k_me16b", "avg_ms": round(st_ms, 4), "achieved": round(st, 1),
+                r["stage"] = {"kernels": "k_bits_cur + " + me_name, "avg_ms": round(st_ms, 4), "achieved": round(st, 1),
                               "frac": round(st / HBM_PEAK_GBS, 4),
                               "traffic": (traffic.get("k_bits_cur", 0) + traffic.get("k_me16b", 0)) or None}
             return r
@@ -670,7 +670,7 @@ def main():
                "the timed loop rotates through %d resident copies of the GOP (cold inputs)"
                % (bs, bs, 2 * bs, round(bs / 3), sets))
         out = {
-            "metric": "macroblocks/ms (16x16, ME+DCT encode) at %s +-32px search" % ("4K" if H >= 2160 else "1080p"),
+            "metric": "macroblocks/ms (%dx%d, ME+DCT encode) at %s +-%dpx search" % (bs, bs, "4K" if H >= 2160 else "1080p", 2 * bs),
             "value": round(value, 2), "unit": "macroblocks/ms",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),

@@ -672,9 +672,12 @@ def test_gop_1080p_rolling_kernel(vh, oracle):
         assert np.array_equal(ns2[keep], ns[keep]) and np.array_equal(mv2[keep], mv[keep])
 
 
-@pytest.mark.parametrize("shape,n", [((360, 640), 7), ((200, 328), 13), ((1080, 1920), 9), ((48, 64), 6), ((144, 176), 33)])
-def test_bitplane_search_gop_batches(vh, oracle, shape, n):
-    """k_bits_ref / k_bits_cur / k_me16b (the default 16x16 search from 6 frames on): batches whose
+@pytest.mark.parametrize("shape,n,bs", [((360, 640), 7, 16), ((200, 328), 13, 16), ((1080, 1920), 9, 16), ((48, 64), 6, 16),
+                                        ((144, 176), 33, 16), ((360, 640), 9, 8), ((200, 328), 17, 8), ((1080, 1920), 8, 8),
+                                        ((24, 32), 8, 8), ((144, 176), 35, 8)])
+def test_bitplane_search_gop_batches(vh, oracle, shape, n, bs):
+    """k_bits_ref / k_bits_cur / k_me16b (the default 16x16 search from 6 frames on) and k_bits_ref8 /
+    k_bits_cur8 / k_me8b (8x8, from 8 frames on; more than 16 frames = two frame groups): batches whose
     frames are dealt to the waves unevenly (7; 13 = 7 + 6; 9 = 5 + 4; 33 = 7 + 7 + 7 + 6 + 6),
     pictures with ragged right / bottom edges and fewer than 64 candidates per block, frames whose
     blocks are mostly static, wholly static or not static at all, cost output on a single frame
@@ -685,13 +688,13 @@ def test_bitplane_search_gop_batches(vh, oracle, shape, n):
     frames = np.ascontiguousarray(frames)
     rng = np.random.default_rng(5)
     for k in (1, 2):                                  # about 70 % / 40 % of the blocks (nearly) static
-        keep = rng.random((H // 16 + 1, W // 16 + 1)) < (0.7 if k == 1 else 0.4)
-        m = np.kron(keep, np.ones((16, 16), bool))[:H, :W]
+        keep = rng.random((H // bs + 1, W // bs + 1)) < (0.7 if k == 1 else 0.4)
+        m = np.kron(keep, np.ones((bs, bs), bool))[:H, :W]
         noisy = np.clip(ref.astype(np.int16) + rng.integers(-1, 2, ref.shape), 0, 255).astype(np.uint8)
         frames[k][m] = noisy[m]
     frames[3] = ref                                   # every block static
     frames[n - 1][: H // 2] = ref[: H // 2]          # the upper half static
-    with vh.Context(H, W, 16) as c:
+    with vh.Context(H, W, bs) as c:
         c.gop_reserve(n)
         c.gop_upload(0, frames)
         for thresh in (2000, 0, 10 ** 9, -1):
@@ -702,16 +705,16 @@ def test_bitplane_search_gop_batches(vh, oracle, shape, n):
             if thresh < 0:                            # nothing is static; frames without zero-difference
                 assert not ns.any()                   # blocks then equal the threshold-0 result
                 for k in (0, 4):
-                    omv, ons = oracle.me(frames[k], ref, 16, thresh=0)
+                    omv, ons = oracle.me(frames[k], ref, bs, thresh=0)
                     assert ons == 0 and np.array_equal(mv[k], omv), (thresh, k)
                 continue
             for k in range(n):
-                omv, ons = oracle.me(frames[k], ref, 16, thresh=min(thresh, 2 ** 32 - 1))
+                omv, ons = oracle.me(frames[k], ref, bs, thresh=min(thresh, 2 ** 32 - 1))
                 assert np.array_equal(mv[k], omv), (thresh, k)
                 assert ns[k] == ons, (thresh, k)
             if thresh == 2000:
                 assert ns[3] == c.N and ns[1] > 0.3 * c.N
-                _, oplanes, _ = oracle.encode_p(frames[n - 1], ref, 16)
+                _, oplanes, _ = oracle.encode_p(frames[n - 1], ref, bs)
                 assert np.array_equal(c.gop_get_planes(n - 1), oplanes)
                 # the same slots again: the static counters restart from zero
                 c.gop_encode(0, n)
@@ -735,7 +738,8 @@ def test_forced_kernel_variants_subprocess():
     # GROUP=0: the private-window rolling kernel (k_me16r); ROLL=0: k_me16 / k_me8
     # BITS=2: the bit-plane search (k_bits_ref, k_bits_cur, k_me16b) on every 16x16 launch, single
     # frames and ragged sizes included; BITS=0: never (the kernels below it run GOP-sized batches too)
-    for env_add, k in (({"VCS_ME16_BITS": "2"}, sel + " or gop_matches_single or bitplane"),
+    for env_add, k in (({"VCS_ME16_BITS": "2", "VCS_ME8_BITS": "2"}, sel + " or gop_matches_single or bitplane"),
+                       ({"VCS_ME8_BITS": "0", "VCS_ME16_ROLL": "2"}, "bitplane or golden_me_small"),
                        ({"VCS_ME16_BITS": "2", "VCS_BITS_PF": "0"}, "gop_1080p_vs_oracle or gop_matches_single"),
                        # the chunk table in many narrow bands of block columns (what 4K does with four)
                        ({"VCS_ME16_BITS": "2", "VCS_BITS_BAND_KB": "1024"}, "bitplane or golden_me_small or gop_1080p_vs_oracle"),

@@ -21,6 +21,7 @@ ap.add_argument("--H", type=int, default=1080)
 ap.add_argument("--W", type=int, default=1920)
 ap.add_argument("--static", type=float, default=0.0, help="fraction of the picture (left part) copied from the reference")
 ap.add_argument("--label", default="")
+ap.add_argument("--bs", type=int, default=16)
 ap.add_argument("--no-events", action="store_true", help="wall time only: no timing events on the kernels")
 a = ap.parse_args()
 
@@ -29,7 +30,7 @@ ref, frames = synth_gop(H, W, n, seed=1234, first=1)
 frames = np.ascontiguousarray(frames)
 if a.static > 0:
     frames[:, :, : int(W * a.static)] = ref[:, : int(W * a.static)]
-with vcs_hip.Context(H, W, 16, 8) as c:
+with vcs_hip.Context(H, W, a.bs, 8) as c:
     c.set_ref(ref)
     c.gop_reserve(a.sets * n)
     for s in range(a.sets):

@@ -22,6 +22,7 @@
 #include "me_group.hpp"
 #include "me_group8.hpp"
 #include "me_bits.hpp"
+#include "me_bits8.hpp"
 #include "me_kernels.hpp"
 #include "me_ext.hpp"
 
@@ -251,7 +252,8 @@ int launch_me_generic_t(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, siz
 // Scratch of the bit-plane search for n frames (grown on demand; allocation synchronises, so it
 // happens on the first launch of a given size only).
 static int ensure_bits(vcs_ctx *c, int n) {
-    if (!c->d_rtab) HIP_TRY(c, hipMalloc(&c->d_rtab, me_bits_rtab_bytes(c->g)));
+    const bool b8 = c->g.bs == 8;   // (a context has one block size: the 8x8 and 16x16 forms never mix)
+    if (!c->d_rtab) HIP_TRY(c, hipMalloc(&c->d_rtab, b8 ? me_bits8_rtab_bytes(c->g) : me_bits_rtab_bytes(c->g)));
     if (n > c->cpl_frames) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         hipFree(c->d_cpl);
@@ -259,8 +261,8 @@ static int ensure_bits(vcs_ctx *c, int n) {
         c->d_cpl = nullptr;
         c->d_binfo = nullptr;
         c->cpl_frames = 0;
-        HIP_TRY(c, hipMalloc(&c->d_cpl, me_bits_cpl_bytes(c->g, n)));
-        HIP_TRY(c, hipMalloc(&c->d_binfo, me_bits_binfo_bytes(c->g, n)));
+        HIP_TRY(c, hipMalloc(&c->d_cpl, b8 ? me_bits8_cpl_bytes(c->g, n) : me_bits_cpl_bytes(c->g, n)));
+        HIP_TRY(c, hipMalloc(&c->d_binfo, b8 ? me_bits8_binfo_bytes(c->g, n) : me_bits_binfo_bytes(c->g, n)));
         c->cpl_frames = n;
     }
     return VCS_OK;
@@ -272,8 +274,9 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     if (c->g.N == 0 || n == 0) return VCS_OK;
     const bool bits = c->me_fast_ok && !force_generic && me_bits_worthwhile(c->g, n);
     // the per-frame static-block counters start at zero; the rolling kernel's primer does it
+    const bool bits8 = c->me_fast8_ok && !force_generic && me_bits8_worthwhile(c->g, n);
     const bool roll = !bits && c->me_fast_ok && !force_generic && me16r_worthwhile(c->g, c->cus, n);
-    if (!roll && !bits) HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
+    if (!roll && !bits && !bits8) HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
     // per-reference sum(r) table, once per reference frame (all P frames of a GOP share it);
     // not part of VCS_T_ME, which times the search kernel alone
     if (!c->sums_valid && !force_generic && (c->me_fast_ok || c->me_fast8_ok)) {
@@ -323,6 +326,27 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         c->t_no_count = nc;
         c->rtab_valid = nb == 1;
         return rc;
+    }
+    if (bits8) {   // the 8x8 bit-plane search (me_bits8.hpp): chunk table per reference, planes, search
+        int rc = ensure_bits(c, n);
+        if (rc) return rc;
+        if (!c->rtab_valid) {
+            launch_bits_ref8(c->g, c->stream, ref, c->Fs + me_fast_ref_slack(c->g), c->d_rtab);
+            HIP_TRY(c, hipGetLastError());
+            c->rtab_valid = true;
+        }
+        uint32_t *ns_part = (uint32_t *)(c->d_binfo + (size_t)n * c->g.N);
+        EvPair evp, ev;
+        if ((rc = t_begin(c, VCS_T_ME_PREP, &evp, /*attach=*/true))) return rc;
+        launch_bits_cur8(c->g, c->stream, curs, stride, ref, n, c->d_cpl, c->d_binfo, ns_part, evp.a, evp.b);
+        if ((rc = t_end(c, &evp))) return rc;
+        static const bool pf_tail_wgs = [] { const char *e = getenv("VCS_BITS_PF"); return !(e && e[0] == '0'); }();
+        const bool pf = c->pf_in_search && pf_tail_wgs && (size_t)n * stride < 0xFFFFFFFFull;
+        c->pf_in_search = pf;
+        if ((rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/true))) return rc;
+        launch_bits_search8(c->g, c->stream, c->d_rtab, c->d_cpl, c->d_binfo, c->d_sums, n, mv, ns_part, ns, cost,
+                            pf ? curs : nullptr, (size_t)n * stride, ev.a, ev.b);
+        return t_end(c, &ev);
     }
     const bool fast16 = c->me_fast_ok && !force_generic;
     const bool group8 = c->me_fast8_ok && !force_generic && me8g_worthwhile(c->g, c->cus, n);
@@ -1233,7 +1257,8 @@ int vcs_gop_encode(vcs_ctx *c, int first, int n) {
     const bool pf_on = pf && chunk * c->Fs <= l3_prefetch_max_bytes();
     // The bit-plane search wants the whole batch (its per-launch tables are repaid by many frames):
     // when it takes it, only the tail goes in cache-sized sub-batches (with the separate prefetch pass)
-    const bool whole_me = chunk < (size_t)n && c->me_fast_ok && me_bits_worthwhile(c->g, n);
+    const bool whole_me = chunk < (size_t)n && ((c->me_fast_ok && me_bits_worthwhile(c->g, n)) ||
+                                                 (c->me_fast8_ok && me_bits8_worthwhile(c->g, n)));
     if (whole_me) {
         c->pf_in_search = false;
         if ((rc = launch_me(c, c->d_ref, curs, c->Fs, n, mv, c->g_ns + first, nullptr))) return rc;
