@@ -587,8 +587,9 @@ def main():
     # the passes the same step runs untimed for ~0.25 s, so that the second pass -- the
     # headline -- is what a stream of GOPs sees; the first is reported beside it.
     # The timed passes carry NO timing events: HIP events attached to the five kernels of a step
-    # cost ~0.04 ms of it (0.705 vs 0.667 ms, measured).  Per-kernel durations (kernel_ms_per_step,
-    # roofline) come from a third pass of the same K steps with the events on.
+    # cost ~0.01 ms of it (0.678 vs 0.667 ms, measured; the in-kernel clock measurement of k_me16b,
+    # once it reported from every workgroup, another 0.03 -- it is sampled now).  Per-kernel durations
+    # (kernel_ms_per_step, roofline) come from a third pass of the same K steps with the events on.
     warm = max(args.warmup, sets if sets > 1 else 0)
     dt0, _, _, _ = timed(sets, args.steps, warm)
     first_pass = {"value": round(n_total * N * args.steps / dt0 / 1e3, 2), "unit": "macroblocks/ms",

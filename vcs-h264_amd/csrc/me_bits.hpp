@@ -301,12 +301,14 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
     }
     uint8_t *const s_c = s_lds + wave * L::kWave;
     uint32_t *const s_part = (uint32_t *)(s_c + L::kPlanes);
-    // units = (block position, frame group), column-major over the block positions (down a block
-    // column the chunk rows of vertically adjacent blocks overlap: they meet in the XCD's L2), dealt
-    // to the 8 XCDs in contiguous ranges; a workgroup = 4 consecutive units (the 4 frame groups of
-    // one block position when ngroups = 4: they read the same chunks through one L1)
-    const int total = na * g.nby * ngroups;   // the band's block positions x frame groups
-    const int chunk = ((total + 7) / 8 + 3) & ~3;
+    // a workgroup = 4 consecutive units (the 4 frame groups of one block position when ngroups = 4:
+    // they read the same chunks through one L1)
+    // units = (block position, frame group); XCD x takes the block columns a0 + x, a0 + x + 8, ... and
+    // walks down each of them (the chunk rows of vertically adjacent blocks overlap: they meet in the
+    // XCD's L2; nothing is shared between columns, so interleaving the columns costs no reuse and
+    // keeps the XCDs equally busy when a region of the picture is static)
+    const int per_col = g.nby * ngroups;
+    const int chunk = (((na + 7) / 8) * per_col + 3) & ~3;   // units per XCD (the XCDs with one column less idle at the end)
     if (blockIdx.x == 0 && a0 == 0) {   // static blocks per frame: the sums of k_bits_cur's per-workgroup counts
         for (int f = wave; f < n_frames; f += 4) {
             uint32_t v = 0;
@@ -317,10 +319,10 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
     }
     const int xcd = blockIdx.x & 7, wg = oct;
     const int ul = wg * 4 + wave;
-    const int u = xcd * chunk + ul;
-    if (ul < chunk && u < total) {
-        const int pos = u / ngroups, grp = u - pos * ngroups;
-        const int bl = pos / g.nby, byi = pos - bl * g.nby, bxi = a0 + bl;   // bl: column inside the band
+    const int lc = ul / per_col, bl = lc * 8 + xcd;   // bl: column inside the band
+    if (ul < chunk && bl < na) {
+        const int rem = ul - lc * per_col;
+        const int byi = rem / ngroups, grp = rem - byi * ngroups, bxi = a0 + bl;
         const int blk = byi * g.nbx + bxi;
         int f0, nf;
         bits_group(n_frames, ngroups, grp, f0, nf);
@@ -511,7 +513,10 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
             if (cost_out) cost_out[o] = cw;
         }
     }
-    if (clk_out && threadIdx.x == 0) {
+    // (one workgroup in 64 reports: 8,040 workgroups adding to the same two words serialise in L2 --
+    // ~12 ns per atomic -- and a wave keeps its slot until its atomics are done: with every workgroup
+    // reporting, the instrumented launch could not end before 8,040 x 25 ns = 0.2 ms)
+    if (clk_out && threadIdx.x == 0 && (blockIdx.x & 63u) == 0) {
         atomicAdd(clk_out + 12, __builtin_amdgcn_s_memtime() - clk0);
         atomicAdd(clk_out + 13, __builtin_amdgcn_s_memrealtime() - rt0);
     }
@@ -597,8 +602,7 @@ inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t
                                const uint8_t *pf_base = nullptr, size_t pf_bytes = 0, hipEvent_t ev_start = nullptr,
                                hipEvent_t ev_stop = nullptr) {
     const int ngroups = me_bits_groups(n);
-    const int total = na * g.nby * ngroups;
-    const int chunk = ((total + 7) / 8 + 3) & ~3;
+    const int chunk = (((na + 7) / 8) * g.nby * ngroups + 3) & ~3;   // units per XCD (k_me16b)
     const int nsearch = 8 * (chunk / 4);
     // prefetch workgroups: octets interleaved 1 : ratio with the last search octets (VCS_BITS_PF_WGS, VCS_BITS_PF_RATIO)
     static const int npf_env = [] { const char *e = getenv("VCS_BITS_PF_WGS"); return e ? atoi(e) : 0; }();

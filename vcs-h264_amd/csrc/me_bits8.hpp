@@ -179,16 +179,16 @@ __global__ __launch_bounds__(256) void k_me8b(const uint32_t *__restrict__ rtab,
             if (lane == 0) n_static[f] = v;
         }
     }
-    // units = (block position, frame group), column-major over the block positions, dealt to the 8
-    // XCDs in contiguous ranges; a workgroup = 4 consecutive units
-    const int total = g.N * ngroups;
-    const int chunk = ((total + 7) / 8 + 3) & ~3;
+    // units = (block position, frame group); XCD x takes the block columns x, x + 8, ... and walks
+    // down each of them (k_me16b: why); a workgroup = 4 consecutive units
+    const int per_col = g.nby * ngroups;
+    const int chunk = (((g.nbx + 7) / 8) * per_col + 3) & ~3;
     const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3;
     const int ul = wg * 4 + wave;
-    const int u = xcd * chunk + ul;
-    if (!(ul < chunk && u < total)) return;
-    const int pos = u / ngroups, grp = u - pos * ngroups;
-    const int bxi = pos / g.nby, byi = pos - bxi * g.nby;
+    const int lc = ul / per_col, bxi = lc * 8 + xcd;
+    if (!(ul < chunk && bxi < g.nbx)) return;
+    const int rem = ul - lc * per_col;
+    const int byi = rem / ngroups, grp = rem - byi * ngroups;
     const int blk = byi * g.nbx + bxi;
     int f0, nf;
     bits_group(n_frames, ngroups, grp, f0, nf);
@@ -338,8 +338,7 @@ inline void launch_bits_search8(const Geom &g, hipStream_t stream, const uint32_
                                 uint32_t *ns, unsigned long long *cost, const uint8_t *pf_base = nullptr,
                                 size_t pf_bytes = 0, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     const int ngroups = me_bits8_groups(n);
-    const int total = g.N * ngroups;
-    const int chunk = ((total + 7) / 8 + 3) & ~3;
+    const int chunk = (((g.nbx + 7) / 8) * g.nby * ngroups + 3) & ~3;   // units per XCD (k_me8b)
     const int nsearch = 8 * (chunk / 4);
     const int npf = pf_base ? 256 : 0;   // prefetch workgroups behind the search's (k_me16b: why 256, why last)
     hipExtLaunchKernelGGL((k_me8b<kBits8NF>), dim3(nsearch + npf), dim3(256), 0, stream, ev_start, ev_stop, 0, rtab, cpl,
