@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ cu
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             const int e = i * 64 + lane;                      // 16-byte piece of the wave's 8 blocks x 48 pieces
-            if (wblk0 + e / 48 < g.N) dst[e] = s_w[e];
+            // (non-temporal: the planes are read back once, 0.1 ms later, by kernels with bandwidth to
+            // spare; step -0.9 % in 4 of 4 A/B pairs)
+            if (wblk0 + e / 48 < g.N) __builtin_nontemporal_store(*(const u32x4_t *)&s_w[e], (u32x4_t *)&dst[e]);
         }
     }
     const bool head = p == 0 && blk < g.N;

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_bits_cur8(const uint8_t *__restrict__ c
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             const int e = i * 64 + lane;                // 16-byte piece of the wave's 32 blocks x 12 pieces
-            if (wblk0 + e / 12 < g.N) dst[e] = s_w[e];
+            if (wblk0 + e / 12 < g.N) __builtin_nontemporal_store(*(const u32x4_t *)&s_w[e], (u32x4_t *)&dst[e]);
         }
     }
     const bool head = q == 0 && blk < g.N;
