@@ -720,6 +720,21 @@ def test_bitplane_search_gop_batches(vh, oracle, shape, n, bs):
                 c.gop_encode(0, n)
                 mv2, ns2 = c.gop_get_mv(0, n)
                 assert np.array_equal(mv2, mv) and np.array_equal(ns2, ns)
+        # the per-reference sum(r) table has two makers (k_me16_sums / k_me8<sums> for single frames, the
+        # batch's own k_bits_ref + k_bits_cur at 16x16): either one's table serves the other's search
+        c.set_params(sim_thresh=2000)
+        c.set_ref(ref)
+        c.gop_encode(0, n)                              # new reference: the batch makes the table
+        m1, s1 = c.me(frames[0])                        # single frame on the same reference
+        assert np.array_equal(m1, oracle.me(frames[0], ref, bs)[0])
+        c.set_ref(frames[4])                            # new reference: the single-frame kernel makes it
+        m2, s2 = c.me(frames[0])
+        assert np.array_equal(m2, oracle.me(frames[0], frames[4], bs)[0])
+        c.gop_encode(0, n)                              # ... and the batch uses it
+        mv3, ns3 = c.gop_get_mv(0, n)
+        for k in (0, n - 1):
+            omv, ons = oracle.me(frames[k], frames[4], bs)
+            assert np.array_equal(mv3[k], omv) and ns3[k] == ons, k
 
 
 def test_forced_kernel_variants_subprocess():

@@ -74,8 +74,11 @@ __device__ __forceinline__ void bits_transpose8(uint32_t (&x)[8]) {
 // start at i_min + 5 ci, of either parity.  One thread per (w, a, m).
 // The table covers a BAND of block columns [a0, a0 + na) (the whole picture when it fits the
 // Infinity Cache beside the planes; 4K goes in four bands): rtab's block-column index is a - a0.
+// r2 (nullable): r2[(w * na + (a - a0)) * 10 + m] = byte sum of the chunk's 96 bytes (rows w, w + 1): eight
+// of them are a candidate's sum(r) (k_bits_cur adds them up: the sum(r) table without k_me16_sums).
 __global__ __launch_bounds__(256) void k_bits_ref(const uint8_t *__restrict__ ref, uint32_t ref_bytes, Geom g,
-                                                  uint32_t *__restrict__ rtab, int a0, int na) {
+                                                  uint32_t *__restrict__ rtab, int a0, int na,
+                                                  uint32_t *__restrict__ r2) {
     const uint32_t total = (uint32_t)g.H * (uint32_t)na * kBitsM;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= total) return;
@@ -89,6 +92,12 @@ __global__ __launch_bounds__(256) void k_bits_ref(const uint8_t *__restrict__ re
     for (int i = 0; i < 12; i++) {   // unaligned dwords (tools/buf_test.hip)
         s[i] = buf_ld32(r_ref, off + 4u * i, 0);
         s[12 + i] = buf_ld32(r_ref, off + (uint32_t)g.pitch + 4u * i, 0);
+    }
+    if (r2) {
+        uint32_t rs = 0;
+#pragma unroll
+        for (int i = 0; i < 24; i++) rs = __builtin_amdgcn_sad_u8(s[i], 0u, rs);
+        r2[idx] = rs;
     }
     uint4 *dst = (uint4 *)(rtab + (size_t)wa * kBitsWA + m * 4);
 #pragma unroll
@@ -114,7 +123,8 @@ constexpr int kBitsCurBlocks = 32;
 __global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ curs, size_t cur_stride,
                                                   const uint8_t *__restrict__ ref, Geom g, int n_frames,
                                                   uint32_t *__restrict__ cpl, uint2 *__restrict__ binfo,
-                                                  uint32_t *__restrict__ ns_part) {
+                                                  uint32_t *__restrict__ ns_part, const uint32_t *__restrict__ r2,
+                                                  uint32_t *__restrict__ sums) {
     __shared__ uint32_t s_ns;
     __shared__ uint4 s_out[4 * 384];
     const int tid = threadIdx.x, p = tid & 7;
@@ -193,6 +203,34 @@ __global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ cu
     // static blocks of this workgroup; k_me16b adds the 8 * per counts of a frame up (no counter to
     // zero before the launch, no atomics on it)
     if (tid == 0) ns_part[(size_t)f * (8 * per) + xcd * per + (idx - f * per)] = s_ns;
+    // The sum(r) table of a new reference (what k_me16_sums makes: sums[blk * 128 + cand] = byte sum of
+    // the candidate's 16 x 48 bytes, 0 for slots without a candidate), by the workgroups of the first
+    // frame: a candidate's sum = 8 row-pair sums of k_bits_ref (r2 != null: the table is due).
+    if (r2 && f == 0) {
+        constexpr int BS = 16, WIN = 32, STEP = 5;
+        const size_t rw = (size_t)g.nbx * kBitsM;   // r2 words per picture row
+#pragma unroll 1
+        for (int it = 0; it < kBitsCurBlocks * kMe16SumStride / 256; it++) {
+            const int e = tid + 256 * it, bi = e / kMe16SumStride, cand = e - bi * kMe16SumStride;
+            const int b = blockIdx_blk0 + bi;
+            if (b >= g.N) continue;
+            const int by = b / g.nbx, bx = b - by * g.nbx;
+            const int x = bx * BS, y = by * BS;
+            const int i_min = max(y - WIN, 0), i_max = min(y + WIN, g.H);
+            const int j_min = max(x - WIN, 0), j_max = min(x + WIN, g.W);
+            const int ri = i_max - BS - i_min, rj = j_max - BS - j_min;
+            const int nci = ri >= 1 ? (ri - 1) / STEP + 1 : 0;
+            const int ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
+            uint32_t v = 0;
+            if (cand < nci * ncj) {
+                const int ci = cand / ncj, cj = cand - ci * ncj;
+                const uint32_t *q = r2 + (size_t)(i_min + STEP * ci) * rw + (size_t)bx * kBitsM + cj;
+#pragma unroll
+                for (int p2 = 0; p2 < 8; p2++) v += q[(size_t)(2 * p2) * rw];
+            }
+            sums[(size_t)b * kMe16SumStride + cand] = v;
+        }
+    }
 }
 
 // ---- the search ---------------------------------------------------------------------------
@@ -550,7 +588,11 @@ inline int me_bits_bands(const Geom &g) {
     return (g.nbx + max_cols - 1) / max_cols;
 }
 inline int me_bits_band_cols(const Geom &g) { const int nb = me_bits_bands(g); return (g.nbx + nb - 1) / nb; }
-inline size_t me_bits_rtab_bytes(const Geom &g) { return (size_t)g.H * me_bits_band_cols(g) * kBitsWA * 4 + 256; }
+inline size_t me_bits_table_words(const Geom &g) { return (size_t)g.H * me_bits_band_cols(g) * kBitsWA; }
+// the chunk table + (one band only) the row-pair sums behind it
+inline size_t me_bits_rtab_bytes(const Geom &g) {
+    return me_bits_table_words(g) * 4 + (size_t)g.H * g.nbx * kBitsM * 4 + 256;
+}
 inline size_t me_bits_cpl_bytes(const Geom &g, int n) { return (size_t)n * g.N * kBitsBlk * 4; }
 inline size_t me_bits_binfo_bytes(const Geom &g, int n) {   // {static-test sum, sum(c)} per block + the static counts per workgroup
     return (size_t)n * g.N * sizeof(uint2) + (size_t)n * (8 * (((g.N + 31) / 32 + 7) / 8)) * sizeof(uint32_t);
@@ -584,19 +626,19 @@ inline bool me_bits_worthwhile(const Geom &g, int n) {
 inline int me_bits_groups(int n) { return (n + kBitsNF - 1) / kBitsNF; }
 
 inline void launch_bits_ref(const Geom &g, hipStream_t stream, const uint8_t *ref, size_t ref_bytes, uint32_t *rtab,
-                            int a0, int na) {
+                            int a0, int na, uint32_t *r2 = nullptr) {
     const uint32_t total = (uint32_t)g.H * (uint32_t)na * kBitsM;
     hipLaunchKernelGGL(k_bits_ref, dim3((total + 255) / 256), dim3(256), 0, stream, ref, (uint32_t)ref_bytes, g, rtab,
-                       a0, na);
+                       a0, na, r2);
 }
 inline int me_bits_cur_wgs(const Geom &g) {   // workgroups of k_bits_cur per frame (a multiple of 8)
     return 8 * (((g.N + kBitsCurBlocks - 1) / kBitsCurBlocks + 7) / 8);
 }
 inline void launch_bits_cur(const Geom &g, hipStream_t stream, const uint8_t *curs, size_t stride, const uint8_t *ref,
-                            int n, uint32_t *cpl, uint2 *binfo, uint32_t *ns_part, hipEvent_t ev_start = nullptr,
-                            hipEvent_t ev_stop = nullptr) {
+                            int n, uint32_t *cpl, uint2 *binfo, uint32_t *ns_part, const uint32_t *r2 = nullptr,
+                            uint32_t *sums = nullptr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     hipExtLaunchKernelGGL(k_bits_cur, dim3(me_bits_cur_wgs(g) * n), dim3(256), 0, stream, ev_start, ev_stop, 0, curs,
-                          stride, ref, g, n, cpl, binfo, ns_part);
+                          stride, ref, g, n, cpl, binfo, ns_part, r2, sums);
 }
 inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t *rtab, const uint32_t *cpl,
                                const uint2 *binfo, const uint32_t *sums, int n, int16_t *mv, const uint32_t *ns_part,

@@ -279,7 +279,10 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     if (!roll && !bits && !bits8) HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
     // per-reference sum(r) table, once per reference frame (all P frames of a GOP share it);
     // not part of VCS_T_ME, which times the search kernel alone
-    if (!c->sums_valid && !force_generic && (c->me_fast_ok || c->me_fast8_ok)) {
+    // (the one-band bit-plane search makes the 16x16 table itself, from k_bits_ref's row-pair sums)
+    const bool fold_sums = bits && !c->sums_valid && me_bits_bands(c->g) == 1;
+    if (fold_sums) c->rtab_valid = false;
+    if (!c->sums_valid && !fold_sums && !force_generic && (c->me_fast_ok || c->me_fast8_ok)) {
         if (c->me_fast_ok) launch_me_fast_sums(c->g, c->stream, c->cus, ref, c->d_sums);
         else launch_me_fast8_sums(c->g, c->stream, c->cus, ref, c->d_sums);
         HIP_TRY(c, hipGetLastError());
@@ -290,11 +293,19 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         int rc = ensure_bits(c, n);
         if (rc) return rc;
         const int nb = me_bits_bands(c->g), bc = me_bits_band_cols(c->g);
+        uint32_t *r2 = c->d_rtab + me_bits_table_words(c->g);   // row-pair sums behind the chunk table
+        if (nb == 1 && !c->rtab_valid) {   // one band: the table of a new reference first (k_bits_cur adds its sums up)
+            launch_bits_ref(c->g, c->stream, ref, c->Fs + me_fast_ref_slack(c->g), c->d_rtab, 0, c->g.nbx, r2);
+            HIP_TRY(c, hipGetLastError());
+            c->rtab_valid = true;
+        }
         EvPair evp;
         if ((rc = t_begin(c, VCS_T_ME_PREP, &evp, /*attach=*/true))) return rc;
         uint32_t *ns_part = (uint32_t *)(c->d_binfo + (size_t)n * c->g.N);   // behind the n * N block records
-        launch_bits_cur(c->g, c->stream, curs, stride, ref, n, c->d_cpl, c->d_binfo, ns_part, evp.a, evp.b);
+        launch_bits_cur(c->g, c->stream, curs, stride, ref, n, c->d_cpl, c->d_binfo, ns_part,
+                        fold_sums ? r2 : nullptr, c->d_sums, evp.a, evp.b);
         if ((rc = t_end(c, &evp))) return rc;
+        if (fold_sums) c->sums_valid = true;
         // The caller's Infinity Cache prefetch of the frames (vcs_gop_encode) rides at the END of the
         // (last) search launch (prefetch workgroups dispatched behind the search's own, me_bits.hpp).
         // Measured alternatives, 29 x 1080p: k_bits_cur's own reads of the frames are gone from the
@@ -311,7 +322,7 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         const bool nc = c->t_no_count;
         for (int band = 0; band < nb && !rc; band++) {
             const int a0 = band * bc, na = std::min(bc, c->g.nbx - a0);
-            if (nb > 1 || !c->rtab_valid) {
+            if (nb > 1) {
                 launch_bits_ref(c->g, c->stream, ref, c->Fs + me_fast_ref_slack(c->g), c->d_rtab, a0, na);
                 HIP_TRY(c, hipGetLastError());
             }
@@ -324,7 +335,7 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
             rc = t_end(c, &ev);
         }
         c->t_no_count = nc;
-        c->rtab_valid = nb == 1;
+        if (nb > 1) c->rtab_valid = false;
         return rc;
     }
     if (bits8) {   // the 8x8 bit-plane search (me_bits8.hpp): chunk table per reference, planes, search
