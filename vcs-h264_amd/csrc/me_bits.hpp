@@ -1,7 +1,7 @@
 // me_bits.hpp -- k_me16b: the 16x16 / +-32 / stride-5 motion search on BIT PLANES.
 //
 // motion.py:146 scores a candidate with sum((ref - cur) mod 256) over 768 bytes, which is
-// sum(r) - sum(c) + 256 * #{r < c}.  sum(r) comes from the per-reference table (k_me16_sums),
+// sum(r) - sum(c) + 256 * #{r < c}.  sum(r) comes from a per-reference table,
 // sum(c) is one number per block, so the work is counting byte pairs with r < c: 76,800
 // pairs per block.  k_me16g counts them four at a time (v_lerp_u8 -> v_and -> v_bcnt, 3
 // vector instructions per 4 pairs).  Here the bytes are stored as bit planes, 32 pairs per
@@ -17,16 +17,20 @@
 //     contiguous across the 10 candidate columns) and keeps it in 24 registers ...
 //   * ... while it loops over the FRAMES of the GOP: all P frames search the same I frame
 //     (encoder.py:51-52), so a wave owns one block position and up to NF frames; the window
-//     operand is loaded once per NF frames;
+//     operand is loaded once per NF frames (double-buffered across row pairs);
 //   * c, the current block: the same for every lane of the wave (one block, one frame, one
 //     row pair) -> scalar registers.  k_bits_cur writes every block of every P frame as 8 row
-//     pairs x 24 plane dwords ("cpl"), the search reads them with s_load; v_bitop3_b32 takes
-//     the plane from an SGPR.  k_bits_cur also does the static test (motion.py:109-116) and
-//     sum(c), and its full-line reads of the frames leave them in the Infinity Cache for the
-//     tail kernel (what k_me16g's in-kernel prefetch did).
-// No LDS, no barrier, no cross-lane traffic until the arg-min.  A static block costs nothing
-// in the search (a scalar branch over its frame), divergence-free.
-// Candidates 64..99 of an interior block run as a second pass with 36 of 64 lanes busy.
+//     pairs x 24 plane dwords ("cpl"), the search reads them with s_load, two frames per
+//     wait; v_bitop3_b32 takes the plane from an SGPR.  k_bits_cur also does the static test
+//     (motion.py:109-116), sum(c) and -- from k_bits_ref's row-pair sums -- the sum(r) table;
+//   * a scalar load that misses L2 takes ~2,000 cycles: one LDS-direct load per row pair,
+//     two row pairs ahead, brings the wave's planes into L2 for the scalar loads AND into
+//     LDS for the second pass;
+//   * candidates 64..99 of an interior block: lane = (candidate, row pair), 288 tasks = 4.5
+//     wave passes, chunk per lane, planes per lane from the LDS copy, counts meet in LDS.
+// No barrier; a static block costs nothing in the search (a scalar branch over its frame),
+// divergence-free.  The launch's last workgroups stream the P frames into the Infinity
+// Cache for the tail kernel.  DESIGN.md 5 has the measurements and what was tried.
 // Results are identical to k_me16 / k_me16g / k_me_generic (tests/test_gpu_parity.py).
 #pragma once
 #include <hip/hip_ext.h>
