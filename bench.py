@@ -70,7 +70,7 @@ def cpu_baseline(H, W, bs, ref, frames, budget_s=10.0):
     structure-faithful NumPy loop (oracle/ref_loop.py, one thread), whose run time is tied
     to the reference's own."""
     from oracle import oracle, ref_loop
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    cores = oracle.usable_cpus(16)
     oracle.set_threads(cores)
     oracle.encode_p(frames[0][:64, :64].copy(), ref[:64, :64].copy(), bs)  # warm (build/load)
     t0 = time.perf_counter()

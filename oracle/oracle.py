@@ -32,18 +32,42 @@ def build(force=False):
     return so
 
 
+def usable_cpus(cap=16):
+    """CPUs this process may really use: the affinity mask, clipped by the cgroup's CPU quota
+    (a GPU box shows every host core in the mask but grants a share of them) and by `cap`."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
+        # one OpenMP thread per usable CPU, sleeping (not spinning) between regions: a team as
+        # large as the host's core count under a 16-CPU share made every small call cost ~0.4 s
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        if "OMP_NUM_THREADS" not in os.environ:
+            os.environ["OMP_NUM_THREADS"] = str(usable_cpus())
         _LIB = ctypes.CDLL(so)
     return _LIB
 
 
 def _p(a, t):
     return a.ctypes.data_as(t) if a is not None else None
+
+
+def _bgr(*frames):
+    for a in frames:
+        if a.ndim != 3 or a.shape[2] != 3 or a.shape != frames[0].shape:
+            raise ValueError("frames must be H x W x 3 and alike, got %r" % (a.shape,))
 
 
 def _c(a, dtype):
@@ -69,6 +93,7 @@ def me(cur, ref, bs, win=None, step=None, thresh=2000, want_cost=False):
     """motion.py:20-36.  Returns (mv int16 N x 2 [dx,dy], n_static[, cost])."""
     cur = _c(cur, np.uint8)
     ref = _c(ref, np.uint8)
+    _bgr(cur, ref)
     H, W = cur.shape[:2]
     win = 2 * bs if win is None else win
     step = default_step(bs) if step is None else step
@@ -88,6 +113,7 @@ def me_ext(cur, ref, bs, search="grid", cost="wrap", win=None, step=None, thresh
            want_cost=False):
     """Extension searches (not in the reference; parity unpinned): vcso_me_ext."""
     cur, ref = _c(cur, np.uint8), _c(ref, np.uint8)
+    _bgr(cur, ref)
     H, W = cur.shape[:2]
     win = 2 * bs if win is None else win
     step = default_step(bs) if step is None else step
@@ -210,6 +236,7 @@ def encode_p(cur, ref, me_bs, Q=None, win=None, step=None, thresh=2000,
     """encoder.py:49-70 with MotionProcessor(me_bs) -> DCTCompressor(8)."""
     cur = _c(cur, np.uint8)
     ref = _c(ref, np.uint8)
+    _bgr(cur, ref)
     H, W = cur.shape[:2]
     win = 2 * me_bs if win is None else win
     step = default_step(me_bs) if step is None else step

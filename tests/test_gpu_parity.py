@@ -748,30 +748,40 @@ def test_forced_kernel_variants_subprocess():
     here = os.path.dirname(os.path.abspath(__file__))
     sel = ("golden_me_small or golden_me_edges or me_vs_oracle_shapes or static_heavy or "
            "4k_frame or empty_and_tiny or golden_real_small or gop_1080p_vs_oracle")
+    sel_small = ("golden_me_small or golden_me_edges or me_vs_oracle_shapes or empty_and_tiny or golden_real_small or "
+                 "gop_1080p_vs_oracle")   # without the 4K frame and the 1080p static-heavy pair (minutes over all variants)
     dct = "golden_dct_small or encode_decode_vs_oracle or dct_extremes or coeff_modes"
     # ROLL=2: the shared-window kernels (k_me16g, k_me8g) on every frame size; ROLL=2 with
     # GROUP=0: the private-window rolling kernel (k_me16r); ROLL=0: k_me16 / k_me8
     # BITS=2: the bit-plane search (k_bits_ref, k_bits_cur, k_me16b) on every 16x16 launch, single
     # frames and ragged sizes included; BITS=0: never (the kernels below it run GOP-sized batches too)
-    for env_add, k in (({"VCS_ME16_BITS": "2", "VCS_ME8_BITS": "2"}, sel + " or gop_matches_single or bitplane"),
+    variants = (({"VCS_ME16_BITS": "2", "VCS_ME8_BITS": "2"}, sel + " or gop_matches_single or bitplane"),
                        ({"VCS_ME8_BITS": "0", "VCS_ME16_ROLL": "2"}, "bitplane or golden_me_small"),
                        ({"VCS_ME16_BITS": "2", "VCS_BITS_PF": "0"}, "gop_1080p_vs_oracle or gop_matches_single"),
                        # the chunk table in many narrow bands of block columns (what 4K does with four)
                        ({"VCS_ME16_BITS": "2", "VCS_BITS_BAND_KB": "1024"}, "bitplane or golden_me_small or gop_1080p_vs_oracle"),
                        ({"VCS_ME16_BITS": "2", "VCS_L3_PREFETCH": "0"}, "gop_1080p_vs_oracle or gop_matches_single"),
                        ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2"}, sel),
-                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "0", "VCS_ME8_GROUP": "0"}, sel),
-                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "2", "VCS_ME16_WPS": "3"}, sel),
-                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "0"}, sel),
-                       ({"VCS_ME_GENERIC": "1"}, sel), ({"VCS_FAST_DIV": "0"}, dct),
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "0", "VCS_ME8_GROUP": "0"}, sel_small),
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_ME16_GROUP": "2", "VCS_ME16_WPS": "3"}, sel_small),
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "0"}, sel_small),
+                       ({"VCS_ME_GENERIC": "1"}, sel_small), ({"VCS_FAST_DIV": "0"}, dct),
                        # the tail kernels' other strip -> workgroup mappings (4 strips per workgroup)
                        ({"VCS_TAIL_MAP": "1"}, dct + " or gop_1080p_vs_oracle"),
                        ({"VCS_TAIL_MAP": "2"}, dct + " or gop_1080p_vs_oracle"),
                        # Infinity Cache prefetch as a separate pass / off (default: inside the search kernel)
                        ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "2"}, "gop_1080p_vs_oracle or gop_matches_single"),
-                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "0"}, "gop_1080p_vs_oracle or gop_matches_single")):
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "0"}, "gop_1080p_vs_oracle or gop_matches_single"))
+
+    def child(v):
+        env_add, k = v
         env = dict(os.environ, **env_add)
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
-                            "-m", "gpu", "-x", "-q", "-k", k, "-p", "no:cacheprovider"],
-                           env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, (env_add, r.stdout[-1500:], r.stderr[-500:])
+        return env_add, subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
+                                        "-m", "gpu", "-x", "-q", "-k", k, "-p", "no:cacheprovider"],
+                                       env=env, capture_output=True, text=True, timeout=900)
+    # three children at a time (a child is mostly start-up: interpreter, library, the first launches);
+    # with this process that is four on the card, inside the box's limit of six
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        for env_add, r in pool.map(child, variants):
+            assert r.returncode == 0, (env_add, r.stdout[-1500:], r.stderr[-500:])
