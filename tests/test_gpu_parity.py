@@ -737,7 +737,7 @@ def test_bitplane_search_gop_batches(vh, oracle, shape, n, bs):
             assert np.array_equal(mv3[k], omv) and ns3[k] == ons, k
 
 
-def test_forced_kernel_variants_subprocess():
+def test_forced_kernel_variants_subprocess(oracle):
     """The same parity cases with every specialised search kernel forced on small and
     ragged frames (VCS_ME16_ROLL=2 and friends), with them disabled (=0), with the generic
     kernel forced (VCS_ME_GENERIC=1), and the DCT cases with the IEEE division
@@ -775,7 +775,7 @@ def test_forced_kernel_variants_subprocess():
 
     def child(v):
         env_add, k = v
-        env = dict(os.environ, **env_add)
+        env = dict(os.environ, VCS_ORACLE_MEMO=oracle._root, **env_add)   # children reuse this session's oracle results
         return env_add, subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
                                         "-m", "gpu", "-x", "-q", "-k", k, "-p", "no:cacheprovider"],
                                        env=env, capture_output=True, text=True, timeout=900)
