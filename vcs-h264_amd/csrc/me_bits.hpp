@@ -210,7 +210,11 @@ __global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ cu
     // The sum(r) table of a new reference (what k_me16_sums makes: sums[blk * 128 + cand] = byte sum of
     // the candidate's 16 x 48 bytes, 0 for slots without a candidate), by the workgroups of the first
     // frame: a candidate's sum = 8 row-pair sums of k_bits_ref (r2 != null: the table is due).
+#ifdef VCS_EXP_BITS_NOFOLD   // experiment builds only (results are wrong): what the folded sum(r) table costs
+    if (false) {
+#else
     if (r2 && f == 0) {
+#endif
         constexpr int BS = 16, WIN = 32, STEP = 5;
         const size_t rw = (size_t)g.nbx * kBitsM;   // r2 words per picture row
 #pragma unroll 1
@@ -279,6 +283,8 @@ __device__ __forceinline__ void bits_ld_chunk(uint32_t (&r)[kBitsT], const uint3
 }
 
 // frames [f0, f0 + nf) of group `grp` when n frames are dealt to `ngroups` waves as evenly as possible
+// (dealing them in pairs -- 29 -> 8, 8, 8, 5, two pair comparisons fewer per candidate than 8, 7, 7, 7
+// -- measures the same: a workgroup lives as long as its longest wave either way)
 __device__ __forceinline__ void bits_group(int n, int ngroups, int grp, int &f0, int &nf) {
     const int q = n / ngroups, r = n - q * ngroups;
     f0 = grp * q + min(grp, r);
@@ -305,7 +311,10 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                                                uint32_t *__restrict__ n_static, int a0, int na) {
     constexpr int BS = 16, WIN = 32, STEP = 5;
     using L = BitsLds<NF>;
-    __shared__ __attribute__((aligned(16))) uint8_t s_lds[4 * L::kWave];
+#ifndef VCS_EXP_BITS_LDSPAD
+#define VCS_EXP_BITS_LDSPAD 0   // experiment builds: extra LDS per workgroup (fewer workgroups per CU)
+#endif
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[4 * L::kWave + VCS_EXP_BITS_LDSPAD];
     // clk_out (timing on): shader-clock cycles and 100 MHz ticks this workgroup lived, summed over
     // the workgroups: their quotient is the clock the chip held under this load
     const unsigned long long clk0 = clk_out ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -366,7 +375,11 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
     const int lc = ul / per_col, bl = lc * 8 + xcd;   // bl: column inside the band
     if (ul < chunk && bl < na) {
         const int rem = ul - lc * per_col;
-        const int byi = rem / ngroups, grp = rem - byi * ngroups, bxi = a0 + bl;
+        const int byi = rem / ngroups, bxi = a0 + bl;
+        // the groups of a position differ in size (29 frames: 8, 7, 7, 7): rotated from position to
+        // position, so that the same wave slot (SIMD) does not get the large one every time (-0.4 % of
+        // the step in 3 of 3 A/B pairs)
+        const int grp = (rem - byi * ngroups + byi) % ngroups;
         const int blk = byi * g.nbx + bxi;
         int f0, nf;
         bits_group(n_frames, ngroups, grp, f0, nf);
@@ -480,7 +493,11 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
             }
 
             // ---- second pass: candidates 64.., lane = (candidate, row pair), planes from LDS ------
+#ifdef VCS_EXP_BITS_NOP2   // experiment builds only (results are wrong): no second pass
+            if (false) {
+#else
             if (ncand > 64) {
+#endif
                 const int n2 = ncand - 64, ntask = 8 * n2;
                 const uint32_t inv_n2 = 65536u / (uint32_t)n2 + 1u;   // t / n2 for t < 288, n2 <= 36
                 if (lane < 40) {

@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void k_me8b(const uint32_t *__restrict__ rtab,
     const int lc = ul / per_col, bxi = lc * 8 + xcd;
     if (!(ul < chunk && bxi < g.nbx)) return;
     const int rem = ul - lc * per_col;
-    const int byi = rem / ngroups, grp = rem - byi * ngroups;
+    const int byi = rem / ngroups;
+    const int grp = (rem - byi * ngroups + byi) % ngroups;   // k_me16b: why
     const int blk = byi * g.nbx + bxi;
     int f0, nf;
     bits_group(n_frames, ngroups, grp, f0, nf);
