@@ -785,3 +785,17 @@ def test_forced_kernel_variants_subprocess(oracle):
     with ThreadPoolExecutor(max_workers=3) as pool:
         for env_add, r in pool.map(child, variants):
             assert r.returncode == 0, (env_add, r.stdout[-1500:], r.stderr[-500:])
+
+
+@pytest.mark.parametrize("env", [{"VCS_ME16_BITS": "2", "VCS_ME8_BITS": "2"}, {}, {"VCS_ME16_BITS": "0", "VCS_ME8_BITS": "0"}])
+def test_randomised_batches_vs_oracle(env):
+    """tools/gpu_fuzz.py: 150 random (size, block size, batch size, threshold, content) cases per kernel
+    selection -- the bit-plane search on every launch, the default selection, the round-2 kernels --
+    vectors and static counts of every frame, one frame's planes in a quarter of the cases."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py"), "--cases", "150", "--seed", "7"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-500:])
