@@ -113,7 +113,7 @@ __device__ __forceinline__ double div_markstein(double a, double b, double y) {
 // then fetches the vector once instead of 8 times (tail 0.335 -> 0.303 ms).
 __device__ __forceinline__ uint32_t pred_mv(const int16_t *__restrict__ mv, const Geom &g, int y, int x) {
     const int yc = min(y, g.nby * g.bs - 1), xc = min(x, g.nbx * g.bs - 1);
-    const int blk = (yc / g.bs) * g.nbx + (xc / g.bs);
+    const int blk = (int)div_magic((uint32_t)yc, g.bs_magic) * g.nbx + (int)div_magic((uint32_t)xc, g.bs_magic);
     return load_px_o((const uint8_t *)mv, 4u * (uint32_t)blk);
 }
 // (the vectors the search kernels produce, and the ones the host lets through, keep the
@@ -140,12 +140,23 @@ __device__ __forceinline__ uint32_t pred_px(const uint8_t *__restrict__ ref,
 //   map 1: XCD x owns a contiguous run of (frame, strip) ids;
 //   map 2: XCD x owns the same band of strips in every frame.
 // The grid is 1-D with tail_grid() workgroups; false = nothing to do.
+// Raster (map 0, the default) launches a 2-D grid -- x: the frame's strips, `waves` per workgroup,
+// y: the frame -- so that the frame is blockIdx.y and the strip's row and 64-pixel group come from
+// one multiply-high (the linear dispatch order is the same raster, x fastest).  Maps 1 and 2 (tests,
+// experiments) keep the 1-D grid and the 64-bit division sequences.
 struct TailUnit { int f, ty, gx; };
-__device__ __forceinline__ bool tail_unit(const Geom &g, int n_frames, int map, TailUnit &u,
-                                          long long L = -1) {
+__device__ __forceinline__ bool tail_unit(const Geom &g, int n_frames, int map, TailUnit &u, int waves, int wave) {
     const int groups_x = (g.W + 63) >> 6, per_frame = groups_x * (g.H >> 3);
+    if (map == 0) {
+        const int s = (int)blockIdx.x * waves + wave;
+        if (s >= per_frame) return false;
+        u.f = (int)blockIdx.y;
+        u.ty = (int)div_magic((uint32_t)s, g.gx_magic);
+        u.gx = s - u.ty * groups_x;
+        return true;
+    }
     const long long total = (long long)per_frame * n_frames;
-    if (L < 0) L = blockIdx.x;
+    long long L = (long long)blockIdx.x * waves + wave;
     long long id;
     if (map == 1) {
         const long long chunk = (total + 7) >> 3;
@@ -158,8 +169,7 @@ __device__ __forceinline__ bool tail_unit(const Geom &g, int n_frames, int map, 
         if (s >= per_frame || i / cs >= n_frames) return false;
         id = (i / cs) * per_frame + s;
     } else {
-        id = L;
-        if (id >= total) return false;
+        return false;
     }
     u.f = (int)(id / per_frame);
     const int s = (int)(id - (long long)u.f * per_frame);
@@ -173,6 +183,13 @@ inline unsigned tail_grid(const Geom &g, int n_frames, int map) {
     if (map == 2) return (unsigned)(8 * ((per_frame + 7) >> 3) * n_frames);
     return (unsigned)(per_frame * n_frames);
 }
+inline dim3 tail_grid_dim(const Geom &g, int n_frames, int map, int waves) {
+    if (map == 0) {
+        const unsigned per_frame = (unsigned)(((g.W + 63) >> 6) * (g.H >> 3));
+        return dim3((per_frame + waves - 1) / waves, (unsigned)n_frames);
+    }
+    return dim3((tail_grid(g, n_frames, map) + waves - 1) / waves);
+}
 
 // The coefficient planes (k_fdct) and the decoded frames (k_idct) are written once and
 // never read back by the kernel that writes them: non-temporal stores keep them from
@@ -181,8 +198,10 @@ inline unsigned tail_grid(const Geom &g, int n_frames, int map) {
 // (0.52 ms): neighbouring lanes' unaligned dword loads share cache lines.
 #ifdef VCS_EXP_PLAIN_STORES   // experiment builds only
 #define VCS_NT_STORE(v, p) (*(p) = (v))
+constexpr int kBufNt = 0;
 #else
 #define VCS_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+constexpr int kBufNt = 2;   // raw buffer aux: bit 1 = nt on gfx940+ (what __builtin_nontemporal_store sets)
 #endif
 template <class T> struct Vec2 { typedef T type __attribute__((ext_vector_type(2))); };
 
@@ -208,7 +227,7 @@ __global__ __launch_bounds__(64 * kFdctWaves) void k_fdct(
     // quantiser table in LDS, staged once per workgroup instead of once per strip.
     __shared__ double s_tw[kFdctWaves][8 * kTilePad];
     __shared__ double s_q[(FASTDIV ? 48 : 24) * kOutPad];  // Q[3][8][8] (then 1/Q), rows padded to 9
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *const s_t = s_tw[wave];
     typename CoeffT<CM>::type *const s_o = (typename CoeffT<CM>::type *)s_t;
     const int t = lane >> 3, j = lane & 7;
@@ -216,10 +235,12 @@ __global__ __launch_bounds__(64 * kFdctWaves) void k_fdct(
     for (int e = threadIdx.x; e < (FASTDIV ? 384 : 192); e += 64 * kFdctWaves)
         s_q[(e >> 3) * kOutPad + (e & 7)] = Qg[e];
     TailUnit tu;
-    const bool has_unit = tail_unit(g, n_frames, map, tu, (long long)blockIdx.x * kFdctWaves + wave);
+    const bool has_unit = tail_unit(g, n_frames, map, tu, kFdctWaves, wave);
     if (kFdctWaves > 1) __syncthreads();   // s_q complete (every wave arrives exactly once)
     if (!has_unit) return;
-    const int ty = tu.ty, gx = tu.gx, f = tu.f;
+    // (wave-uniform by construction; said so, they and everything derived from them live in SGPRs)
+    const int ty = __builtin_amdgcn_readfirstlane(tu.ty), gx = __builtin_amdgcn_readfirstlane(tu.gx),
+              f = __builtin_amdgcn_readfirstlane(tu.f);
     const int x = gx * 64 + lane;  // stage-1 pixel column of this lane
     const uint8_t *__restrict__ img = imgs + (size_t)f * img_stride;
     const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
@@ -315,40 +336,57 @@ __global__ __launch_bounds__(64 * kFdctWaves) void k_fdct(
 // k_idct: DCTCompressor.decompress (DCTcompressor.py:76-93); MODE 1 adds the
 // motion-compensated prediction with uint8 wrap (decoder.py:52-69).
 // --------------------------------------------------------------------------
-template <int MODE, int CM>
-__global__ __launch_bounds__(64 * kIdctWaves) void k_idct(
+#ifdef VCS_EXP_IDCT_WPE   // experiment builds: occupancy hint for k_idct
+#define IDCT_WPE __attribute__((amdgpu_waves_per_eu(VCS_EXP_IDCT_WPE, 8)))
+#else
+#define IDCT_WPE
+#endif
+// ONEBLK (host: MODE == 1 and bs % 8 == 0, every BASELINE configuration): the 8 pixels a lane
+// reconstructs share one motion block -- one vector load, issued first
+template <int MODE, int CM, bool ONEBLK = false>
+__global__ __launch_bounds__(64 * kIdctWaves) IDCT_WPE void k_idct(
     const typename CoeffT<CM>::type *__restrict__ planes, size_t planes_stride,
     const uint8_t *__restrict__ ref, const int16_t *__restrict__ mvs, Geom g,
     const double *__restrict__ DQ, uint8_t *__restrict__ outs, size_t out_stride, int n_frames,
     int map) {
     __shared__ double s_tw[kIdctWaves][8 * kTilePad];   // one strip per wave, as in k_fdct
     __shared__ double s_q[24 * kOutPad];  // Q[3][8][8], rows padded to 9
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *const s_t = s_tw[wave];
     const int t = lane >> 3, j = lane & 7;
     for (int e = threadIdx.x; e < 192; e += 64 * kIdctWaves) s_q[(e >> 3) * kOutPad + (e & 7)] = DQ[64 + e];
     TailUnit tu;
-    const bool has_unit = tail_unit(g, n_frames, map, tu, (long long)blockIdx.x * kIdctWaves + wave);
+    const bool has_unit = tail_unit(g, n_frames, map, tu, kIdctWaves, wave);
     if (kIdctWaves > 1) __syncthreads();
     if (!has_unit) return;
-    const int ty = tu.ty, gx = tu.gx, f = tu.f;
+    const int ty = __builtin_amdgcn_readfirstlane(tu.ty), gx = __builtin_amdgcn_readfirstlane(tu.gx),
+              f = __builtin_amdgcn_readfirstlane(tu.f);
     const int x = gx * 64 + lane;
     const int xl = min(x, g.W - 1);  // lanes past the frame edge: clamped loads, no stores
     const size_t plane = (size_t)g.H * g.W;
     const typename CoeffT<CM>::type *__restrict__ in = planes + (size_t)f * planes_stride;
     const int16_t *__restrict__ mv = MODE ? mvs + (size_t)f * g.N * 2 : nullptr;
     // ---- every global load up front, branch-free ----------------------------------
+    // stage-2 ownership: row j of tile t -> 8 pixels starting at column xo
+    const int y = ty * 8 + j, xo = min(gx * 64 + t * 8, g.W - 8);
+    // The block's vector first, the planes behind it, the 8 predicted pixels (which need the vector,
+    // not the planes: loads return in order) behind those -- and nothing that could move them: the
+    // kernel has no branch after this point (lanes past the frame edge store out of the buffer's
+    // range, which the hardware drops), because hipcc sinks loads into the block of their first use;
+    // with the early return of the first version the 16 vector / pixel loads sat behind the whole
+    // IDCT and every wave ended in two dependent round trips (0.345 -> 0.3xx ms per 29 frames).
+    const uint32_t m8 = ONEBLK ? pred_mv(mv, g, y, xo) : 0u;
     double X[3][8];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++)
 #pragma unroll
         for (int k = 0; k < 8; k++)
             X[ch][k] = (double)in[ch * plane + (size_t)(ty * 8 + k) * g.W + xl];
-    // stage-2 ownership: row j of tile t -> 8 pixels starting at column xo
-    const int y = ty * 8 + j, xo = min(gx * 64 + t * 8, g.W - 8);
     uint32_t pp[8];
 #pragma unroll
-    for (int jj = 0; jj < 8; jj++) pp[jj] = MODE == 1 ? pred_px(ref, mv, g, y, xo + jj) : 0u;   // (one vector load for the 8 pixels was measured: 6 % slower, the chain gets longer)
+    for (int jj = 0; jj < 8; jj++)
+        pp[jj] = MODE != 1 ? 0u : ONEBLK ? pred_px_m(ref, g, y, xo + jj, m8) : pred_px(ref, mv, g, y, xo + jj);
+    __builtin_amdgcn_sched_barrier(0);
     wave_lds_fence();
 
     int ycc[3][8];  // row i = j of the tile, 8 pixels, after stage 2
@@ -379,7 +417,6 @@ __global__ __launch_bounds__(64 * kIdctWaves) void k_idct(
             ycc[ch][jj] = ((int)acc + 128) & 255;
         }
     }
-    if (gx * 64 + t * 8 >= g.W) return;
     // 8 pixels = 24 bytes, packed into three 8-byte stores (24*t is 8-byte aligned)
     uint8_t b[24];
 #pragma unroll
@@ -392,13 +429,16 @@ __global__ __launch_bounds__(64 * kIdctWaves) void k_idct(
         b[3 * jj + 2] = (uint8_t)(R + (int)((p >> 16) & 255));
     }
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 *o = (u32x2 *)(outs + (size_t)f * out_stride + (size_t)y * g.pitch + (size_t)(3 * xo));
+    // tiles past the right edge (W not a multiple of 64): an offset beyond the frame, dropped by the
+    // buffer's range check -- no branch (see above)
+    const __amdgpu_buffer_rsrc_t r_out = buf_rsrc(outs + (size_t)f * out_stride, (uint32_t)(g.H * g.pitch));
+    const uint32_t oo = gx * 64 + t * 8 < g.W ? (uint32_t)(y * g.pitch + 3 * xo) : 0xFFFFFF00u;
 #pragma unroll
     for (int q = 0; q < 3; q++) {
         u32x2 v;
         v.x = b[8 * q] | (b[8 * q + 1] << 8) | (b[8 * q + 2] << 16) | ((uint32_t)b[8 * q + 3] << 24);
         v.y = b[8 * q + 4] | (b[8 * q + 5] << 8) | (b[8 * q + 6] << 16) | ((uint32_t)b[8 * q + 7] << 24);
-        VCS_NT_STORE(v, o + q);
+        __builtin_amdgcn_raw_buffer_store_b64(v, r_out, (int)(oo + 8u * q), 0, kBufNt);
     }
 }
 

@@ -429,7 +429,7 @@ int launch_fdct(vcs_ctx *c, int tslot, const uint8_t *imgs, size_t stride, const
     if (n == 0) return VCS_OK;
     const Geom &g = c->g;
     const int map = tail_map();
-    dim3 grid((tail_grid(g, n, map) + kFdctWaves - 1) / kFdctWaves), block(64 * kFdctWaves);
+    const dim3 grid = tail_grid_dim(g, n, map, kFdctWaves), block(64 * kFdctWaves);
     EvPair ev;
     int rc = t_begin(c, tslot, &ev, /*attach=*/true);
     if (rc) return rc;
@@ -457,27 +457,26 @@ int launch_idct(vcs_ctx *c, int tslot, const void *planes, size_t pstride_elems,
     if (n == 0) return VCS_OK;
     const Geom &g = c->g;
     const int map = tail_map();
-    dim3 grid((tail_grid(g, n, map) + kIdctWaves - 1) / kIdctWaves), block(64 * kIdctWaves);
+    const dim3 grid = tail_grid_dim(g, n, map, kIdctWaves), block(64 * kIdctWaves);
     EvPair ev;
     int rc = t_begin(c, tslot, &ev, /*attach=*/true);
     if (rc) return rc;
+    const bool one = MODE == 1 && g.bs % 8 == 0;   // a lane's 8 pixels share one motion block
+#define VCS_IDCT(CM, T, ONE)                                                                        \
+    hipExtLaunchKernelGGL((k_idct<MODE, CM, ONE>), grid, block, 0, c->stream, ev.a, ev.b, 0,        \
+                          (const T *)planes, pstride_elems, ref, mv, g, c->d_DQ, outs, ostride, n, map)
     switch (c->coeff_mode) {
         case VCS_COEFF_F64:
-            hipExtLaunchKernelGGL((k_idct<MODE, 0>), grid, block, 0, c->stream, ev.a, ev.b, 0,
-                                  (const double *)planes, pstride_elems, ref, mv, g, c->d_DQ, outs,
-                                  ostride, n, map);
+            if (one) VCS_IDCT(0, double, MODE == 1); else VCS_IDCT(0, double, false);
             break;
         case VCS_COEFF_F32:
-            hipExtLaunchKernelGGL((k_idct<MODE, 1>), grid, block, 0, c->stream, ev.a, ev.b, 0,
-                                  (const float *)planes, pstride_elems, ref, mv, g, c->d_DQ, outs,
-                                  ostride, n, map);
+            if (one) VCS_IDCT(1, float, MODE == 1); else VCS_IDCT(1, float, false);
             break;
         default:
-            hipExtLaunchKernelGGL((k_idct<MODE, 2>), grid, block, 0, c->stream, ev.a, ev.b, 0,
-                                  (const int16_t *)planes, pstride_elems, ref, mv, g, c->d_DQ, outs,
-                                  ostride, n, map);
+            if (one) VCS_IDCT(2, int16_t, MODE == 1); else VCS_IDCT(2, int16_t, false);
             break;
     }
+#undef VCS_IDCT
     return t_end(c, &ev);
 }
 
@@ -748,6 +747,8 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     Geom &g = c->g;
     g.H = H; g.W = W; g.pitch = 3 * W; g.bs = me_bs;
     g.nbx = W / me_bs; g.nby = H / me_bs; g.N = g.nbx * g.nby;
+    g.bs_magic = magic_u32((uint32_t)me_bs);
+    g.gx_magic = magic_u32((uint32_t)((W + 63) >> 6));
     g.win = 2 * me_bs;               // motion.py:18
     g.step = py_round_div3(me_bs);   // motion.py:132
     c->thresh64 = 2000;              // motion.py:8

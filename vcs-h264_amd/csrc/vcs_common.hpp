@@ -15,7 +15,20 @@ struct Geom {
     uint32_t thresh; // static threshold (motion.py:8), clamped to u32
     int never_static;// thresh < 0: no block can be static
     int wpitch;      // LDS bytes per staged window row (generic ME kernel)
+    // x / bs and strip / groups_x for the tail kernels without a division sequence (magic_u32 below)
+    uint32_t bs_magic, gx_magic;
 };
+
+// x / d for x * d < 2^32 as one v_mul_hi_u32 / s_mul_hi_u32: magic = floor(2^32 / d) + 1 (d >= 2);
+// magic 0 stands for d = 1.  (magic * d = 2^32 + e with 0 < e <= d, so the product's high word is
+// floor(x / d + x e / (d 2^32)) and x e < 2^32 keeps the second term below 1 / d.)  The runtime
+// divisors of the tail kernels -- motion block size, 64-pixel groups per row -- took ~25 vector
+// instructions per division, a third of k_idct's and a quarter of k_fdct's instructions before the
+// first load was issued.
+inline uint32_t magic_u32(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d + 1ull); }
+__device__ __forceinline__ uint32_t div_magic(uint32_t x, uint32_t magic) {
+    return magic ? __umulhi(x, magic) : x;
+}
 
 // ---- wave64 reductions ---------------------------------------------------
 // DPP inside each 16-lane row (4 VALU ops, no LDS crossbar round trips), then
