@@ -376,12 +376,30 @@ __global__ __launch_bounds__(64 * kIdctWaves) IDCT_WPE void k_idct(
     // with the early return of the first version the 16 vector / pixel loads sat behind the whole
     // IDCT and every wave ended in two dependent round trips (0.345 -> 0.3xx ms per 29 frames).
     const uint32_t m8 = ONEBLK ? pred_mv(mv, g, y, xo) : 0u;
+    // (buffer loads: one lane offset for all 24, the row / channel offsets are scalar -- the flat form
+    // spends a 64-bit vector add and a register pair per load)
     double X[3][8];
+    {
+        using T = typename CoeffT<CM>::type;
+        const uint32_t esz = (uint32_t)sizeof(T);
+        const __amdgpu_buffer_rsrc_t r_in = buf_rsrc(in, (uint32_t)min((size_t)0xFFFFFFF0u, 3 * plane * esz));
+        const uint32_t voff = (uint32_t)xl * esz;
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++)
+        for (int ch = 0; ch < 3; ch++)
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            X[ch][k] = (double)in[ch * plane + (size_t)(ty * 8 + k) * g.W + xl];
+            for (int k = 0; k < 8; k++) {
+                const uint32_t soff = ((uint32_t)ch * (uint32_t)plane + (uint32_t)(ty * 8 + k) * (uint32_t)g.W) * esz;
+                if constexpr (CM == 0) {
+                    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+                    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_in, (int)voff, (int)soff, 0);
+                    X[ch][k] = __builtin_bit_cast(double, v);
+                } else if constexpr (CM == 1) {
+                    X[ch][k] = (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_in, (int)voff, (int)soff, 0));
+                } else {
+                    X[ch][k] = (double)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(r_in, (int)voff, (int)soff, 0);
+                }
+            }
+    }
     uint32_t pp[8];
 #pragma unroll
     for (int jj = 0; jj < 8; jj++)

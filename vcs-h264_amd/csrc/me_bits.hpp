@@ -285,8 +285,8 @@ __device__ __forceinline__ void bits_ld_chunk(uint32_t (&r)[kBitsT], const uint3
 // frames [f0, f0 + nf) of group `grp` when n frames are dealt to `ngroups` waves as evenly as possible
 // (dealing them in pairs -- 29 -> 8, 8, 8, 5, two pair comparisons fewer per candidate than 8, 7, 7, 7
 // -- measures the same: a workgroup lives as long as its longest wave either way)
-__device__ __forceinline__ void bits_group(int n, int ngroups, int grp, int &f0, int &nf) {
-    const int q = n / ngroups, r = n - q * ngroups;
+__device__ __forceinline__ void bits_group(int n, int ngroups, uint32_t ngroups_magic, int grp, int &f0, int &nf) {
+    const int q = (int)div_magic((uint32_t)n, ngroups_magic), r = n - q * ngroups;
     f0 = grp * q + min(grp, r);
     nf = q + (grp < r ? 1 : 0);
 }
@@ -308,7 +308,10 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
                                                const uint8_t *__restrict__ pf_base, uint32_t pf_total16,
                                                int n_search_wgs, int pf_octets, int pf_ratio,
                                                const uint32_t *__restrict__ ns_part, int ns_per_frame,
-                                               uint32_t *__restrict__ n_static, int a0, int na) {
+                                               uint32_t *__restrict__ n_static, int a0, int na,
+                                               uint32_t per_col_magic, uint32_t ngroups_magic) {
+    // (per_col_magic, ngroups_magic: magic_u32 of nby * ngroups and of ngroups -- the unit decode below
+    // is scalar, and a scalar division by a runtime value is a 25-instruction vector sequence)
     constexpr int BS = 16, WIN = 32, STEP = 5;
     using L = BitsLds<NF>;
 #ifndef VCS_EXP_BITS_LDSPAD
@@ -372,17 +375,18 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
     }
     const int xcd = blockIdx.x & 7, wg = oct;
     const int ul = wg * 4 + wave;
-    const int lc = ul / per_col, bl = lc * 8 + xcd;   // bl: column inside the band
+    const int lc = (int)div_magic((uint32_t)ul, per_col_magic), bl = lc * 8 + xcd;   // bl: column inside the band
     if (ul < chunk && bl < na) {
         const int rem = ul - lc * per_col;
-        const int byi = rem / ngroups, bxi = a0 + bl;
+        const int byi = (int)div_magic((uint32_t)rem, ngroups_magic), bxi = a0 + bl;
         // the groups of a position differ in size (29 frames: 8, 7, 7, 7): rotated from position to
         // position, so that the same wave slot (SIMD) does not get the large one every time (-0.4 % of
         // the step in 3 of 3 A/B pairs)
-        const int grp = (rem - byi * ngroups + byi) % ngroups;
+        const int gr = rem - byi * ngroups + byi;
+        const int grp = gr - ngroups * (int)div_magic((uint32_t)gr, ngroups_magic);
         const int blk = byi * g.nbx + bxi;
         int f0, nf;
-        bits_group(n_frames, ngroups, grp, f0, nf);
+        bits_group(n_frames, ngroups, ngroups_magic, grp, f0, nf);
         const int x = bxi * BS, y = byi * BS;
         const int i_min = max(y - WIN, 0), i_max = min(y + WIN, g.H);
         const int j_min = max(x - WIN, 0), j_max = min(x + WIN, g.W);
@@ -682,7 +686,7 @@ inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t
     hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(nsearch + 8 * pf8), dim3(256), 0, stream, ev_start, ev_stop, 0,
                           rtab, cpl, binfo, sums, g, n, ngroups, mv, cost, clk, pf_base,
                           (uint32_t)(pf_base ? pf_bytes >> 4 : 0), nsearch, pf8, ratio, ns_part, me_bits_cur_wgs(g), ns,
-                          a0, na);
+                          a0, na, magic_u32((uint32_t)(g.nby * ngroups)), magic_u32((uint32_t)ngroups));
 }
 
 }  // namespace vcs

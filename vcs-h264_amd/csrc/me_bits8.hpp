@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void k_me8b(const uint32_t *__restrict__ rtab,
                                               unsigned long long *__restrict__ cost_out,
                                               const uint8_t *__restrict__ pf_base, uint32_t pf_total16,
                                               int n_search_wgs, const uint32_t *__restrict__ ns_part,
-                                              int ns_per_frame, uint32_t *__restrict__ n_static) {
+                                              int ns_per_frame, uint32_t *__restrict__ n_static,
+                                              uint32_t per_col_magic, uint32_t ngroups_magic) {
     constexpr int BS = 8, WIN = 16, STEP = 3;
     __shared__ __attribute__((aligned(16))) uint8_t s_dump[4 * 1024];   // where prefetched bytes go: nobody reads it
     const int lane = threadIdx.x & 63;
@@ -185,14 +186,15 @@ __global__ __launch_bounds__(256) void k_me8b(const uint32_t *__restrict__ rtab,
     const int chunk = (((g.nbx + 7) / 8) * per_col + 3) & ~3;
     const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3;
     const int ul = wg * 4 + wave;
-    const int lc = ul / per_col, bxi = lc * 8 + xcd;
+    const int lc = (int)div_magic((uint32_t)ul, per_col_magic), bxi = lc * 8 + xcd;
     if (!(ul < chunk && bxi < g.nbx)) return;
     const int rem = ul - lc * per_col;
-    const int byi = rem / ngroups;
-    const int grp = (rem - byi * ngroups + byi) % ngroups;   // k_me16b: why
+    const int byi = (int)div_magic((uint32_t)rem, ngroups_magic);
+    const int gr = rem - byi * ngroups + byi;   // k_me16b: why
+    const int grp = gr - ngroups * (int)div_magic((uint32_t)gr, ngroups_magic);
     const int blk = byi * g.nbx + bxi;
     int f0, nf;
-    bits_group(n_frames, ngroups, grp, f0, nf);
+    bits_group(n_frames, ngroups, ngroups_magic, grp, f0, nf);
     const int x = bxi * BS, y = byi * BS;
     const int i_min = max(y - WIN, 0), i_max = min(y + WIN, g.H);
     const int j_min = max(x - WIN, 0), j_max = min(x + WIN, g.W);
@@ -344,7 +346,7 @@ inline void launch_bits_search8(const Geom &g, hipStream_t stream, const uint32_
     const int npf = pf_base ? 256 : 0;   // prefetch workgroups behind the search's (k_me16b: why 256, why last)
     hipExtLaunchKernelGGL((k_me8b<kBits8NF>), dim3(nsearch + npf), dim3(256), 0, stream, ev_start, ev_stop, 0, rtab, cpl,
                           binfo, sums, g, n, ngroups, mv, cost, pf_base, (uint32_t)(pf_base ? pf_bytes >> 4 : 0), nsearch,
-                          ns_part, me_bits8_cur_wgs(g), ns);
+                          ns_part, me_bits8_cur_wgs(g), ns, magic_u32((uint32_t)(g.nby * ngroups)), magic_u32((uint32_t)ngroups));
 }
 
 }  // namespace vcs
