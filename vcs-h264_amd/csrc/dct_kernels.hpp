@@ -27,9 +27,9 @@ constexpr int kOutPad = 9;    // elements per output row in the LDS store buffer
 #endif
 constexpr int kFdctWaves = VCS_FDCT_WAVES;  // strips (waves) per k_fdct workgroup
 #ifndef VCS_IDCT_WAVES
-#define VCS_IDCT_WAVES 1
+#define VCS_IDCT_WAVES 4
 #endif
-constexpr int kIdctWaves = VCS_IDCT_WAVES;   // k_idct is bound by its 1.44 GB of plane reads: 1, 2, 4 waves measure the same
+constexpr int kIdctWaves = VCS_IDCT_WAVES;   // strips (waves) per k_idct workgroup: 1 / 2 / 4 = 0.311 / 0.299 / 0.298 ms (round 3, with non-temporal plane loads)
 
 // coefficient store / load for the three coefficient modes (vcs_hip.h)
 template <int CM> struct CoeffT;
@@ -384,6 +384,9 @@ __global__ __launch_bounds__(64 * kIdctWaves) IDCT_WPE void k_idct(
         const uint32_t esz = (uint32_t)sizeof(T);
         const __amdgpu_buffer_rsrc_t r_in = buf_rsrc(in, (uint32_t)min((size_t)0xFFFFFFF0u, 3 * plane * esz));
         const uint32_t voff = (uint32_t)xl * esz;
+        // the planes are read once: non-temporal loads (with four strips per workgroup: 0.315 -> 0.298 ms;
+        // either alone: -2 / -3 %).  VCS_EXP_PLAIN_STORES builds drop the hint with the stores'.
+        constexpr int kAux = kBufNt;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++)
 #pragma unroll
@@ -391,12 +394,12 @@ __global__ __launch_bounds__(64 * kIdctWaves) IDCT_WPE void k_idct(
                 const uint32_t soff = ((uint32_t)ch * (uint32_t)plane + (uint32_t)(ty * 8 + k) * (uint32_t)g.W) * esz;
                 if constexpr (CM == 0) {
                     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-                    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_in, (int)voff, (int)soff, 0);
+                    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r_in, (int)voff, (int)soff, kAux);
                     X[ch][k] = __builtin_bit_cast(double, v);
                 } else if constexpr (CM == 1) {
-                    X[ch][k] = (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_in, (int)voff, (int)soff, 0));
+                    X[ch][k] = (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_in, (int)voff, (int)soff, kAux));
                 } else {
-                    X[ch][k] = (double)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(r_in, (int)voff, (int)soff, 0);
+                    X[ch][k] = (double)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(r_in, (int)voff, (int)soff, kAux);
                 }
             }
     }
