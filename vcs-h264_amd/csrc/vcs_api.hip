@@ -456,6 +456,9 @@ int launch_idct(vcs_ctx *c, int tslot, const void *planes, size_t pstride_elems,
                 const uint8_t *ref, const int16_t *mv, int n, uint8_t *outs, size_t ostride) {
     if (n == 0) return VCS_OK;
     const Geom &g = c->g;
+    // k_idct addresses a frame's planes with 32-bit byte offsets (buffer loads)
+    if ((unsigned long long)3 * g.H * g.W * 8 > 0xFFFFFFF0ull)
+        return fail(c, VCS_E_ARG, "%dx%d: the decode path takes frames up to 178 Mpixel", g.W, g.H);
     const int map = tail_map();
     const dim3 grid = tail_grid_dim(g, n, map, kIdctWaves), block(64 * kIdctWaves);
     EvPair ev;
