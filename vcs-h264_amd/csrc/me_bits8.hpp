@@ -16,7 +16,8 @@
 //     but four times as many blocks carry the per-block fixed work (unit decode, arg-min, result), so
 //     a wave takes up to 16 frames.
 // k_bits_cur8 makes the planes, the static test and sum(c) (one thread per (block, row quad)),
-// k_bits_ref8 the chunk table, the sum(r) table is k_me8<kMe8Sums>'s.
+// k_bits_ref8 the chunk table and its chunk sums, from which the first frame's workgroups of k_bits_cur8 add
+// up the sum(r) table of a new reference (k_me8<kMe8Sums> makes it for the single-frame kernels).
 // Results are identical to k_me8 / k_me8g / k_me_generic (tests/test_gpu_parity.py).
 #pragma once
 #include "me_bits.hpp"
@@ -32,8 +33,10 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 // rtab[((w * nbx + a) * 6 + q) * 32 + m * 4 + e] = plane dword t = 4 q + e of the 96-byte string
 // rows w .. w + 3, bytes 3 j .. 3 j + 23 each, j = max(8 a - 16, 0) + 3 m.  One thread per (w, a, m).
+// r2 (nullable): r2[(w * nbx + a) * 8 + m] = byte sum of the chunk's 96 bytes: two of them, four rows apart,
+// are a candidate's sum(r) (k_bits_cur8 adds them up: the sum(r) table without k_me8<kMe8Sums>'s launch).
 __global__ __launch_bounds__(256) void k_bits_ref8(const uint8_t *__restrict__ ref, uint32_t ref_bytes, Geom g,
-                                                   uint32_t *__restrict__ rtab) {
+                                                   uint32_t *__restrict__ rtab, uint32_t *__restrict__ r2) {
     const uint32_t total = (uint32_t)g.H * (uint32_t)g.nbx * kBits8M;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= total) return;
@@ -47,6 +50,12 @@ __global__ __launch_bounds__(256) void k_bits_ref8(const uint8_t *__restrict__ r
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int i = 0; i < 6; i++) s[6 * r + i] = buf_ld32(r_ref, off + (uint32_t)r * (uint32_t)g.pitch + 4u * i, 0);
+    if (r2) {
+        uint32_t rs = 0;
+#pragma unroll
+        for (int i = 0; i < 24; i++) rs = __builtin_amdgcn_sad_u8(s[i], 0u, rs);
+        r2[idx] = rs;
+    }
     uint4 *dst = (uint4 *)(rtab + (size_t)wa * kBits8WA + m * 4);
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -68,7 +77,8 @@ constexpr int kBits8CurBlocks = 128;
 __global__ __launch_bounds__(256) void k_bits_cur8(const uint8_t *__restrict__ curs, size_t cur_stride,
                                                    const uint8_t *__restrict__ ref, Geom g, int n_frames,
                                                    uint32_t *__restrict__ cpl, uint2 *__restrict__ binfo,
-                                                   uint32_t *__restrict__ ns_part) {
+                                                   uint32_t *__restrict__ ns_part, const uint32_t *__restrict__ r2,
+                                                   uint32_t *__restrict__ sums) {
     __shared__ uint32_t s_ns;
     __shared__ uint4 s_out[4 * 384];
     const int tid = threadIdx.x, q = tid & 1;
@@ -136,6 +146,33 @@ __global__ __launch_bounds__(256) void k_bits_cur8(const uint8_t *__restrict__ c
     if ((tid & 63) == 0 && st) atomicAdd(&s_ns, (uint32_t)__builtin_popcountll(st));
     __syncthreads();
     if (tid == 0) ns_part[(size_t)f * (8 * per) + xcd * per + (idx - f * per)] = s_ns;
+    // The sum(r) table of a new reference (what k_me8<kMe8Sums> makes: sums[blk * 64 + cand] = byte sum of the
+    // candidate's 8 x 24 bytes, 0 for slots without a candidate), by the workgroups of the first frame: a
+    // candidate's sum = the chunk sums of its two row quads (r2 != null: the table is due).  As k_bits_cur.
+    if (r2 && f == 0) {
+        constexpr int BS = 8, WIN = 16, STEP = 3;
+        const size_t rw = (size_t)g.nbx * kBits8M;   // r2 words per picture row
+#pragma unroll 1
+        for (int it = 0; it < kBits8CurBlocks * kMe8SumStride / 256; it++) {
+            const int e = tid + 256 * it, bi = e / kMe8SumStride, cand = e - bi * kMe8SumStride;
+            const int b = wg_blk0 + bi;
+            if (b >= g.N) continue;
+            const int by = b / g.nbx, bx = b - by * g.nbx;
+            const int x = bx * BS, y = by * BS;
+            const int i_min = max(y - WIN, 0), i_max = min(y + WIN, g.H);
+            const int j_min = max(x - WIN, 0), j_max = min(x + WIN, g.W);
+            const int ri = i_max - BS - i_min, rj = j_max - BS - j_min;
+            const int nci = ri >= 1 ? (ri - 1) / STEP + 1 : 0;
+            const int ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
+            uint32_t v = 0;
+            if (cand < nci * ncj) {
+                const int ci = cand / ncj, cj = cand - ci * ncj;
+                const uint32_t *p2 = r2 + (size_t)(i_min + STEP * ci) * rw + (size_t)bx * kBits8M + cj;
+                v = p2[0] + p2[4 * rw];
+            }
+            sums[(size_t)b * kMe8SumStride + cand] = v;
+        }
+    }
 }
 
 #ifndef VCS_BITS8_NF
@@ -295,7 +332,11 @@ __global__ __launch_bounds__(256) void k_me8b(const uint32_t *__restrict__ rtab,
 }
 
 // ---- host side ----------------------------------------------------------------------------
-inline size_t me_bits8_rtab_bytes(const Geom &g) { return (size_t)g.H * g.nbx * kBits8WA * 4 + 256; }
+inline size_t me_bits8_table_words(const Geom &g) { return (size_t)g.H * g.nbx * kBits8WA; }
+// the chunk table + the chunk sums behind it
+inline size_t me_bits8_rtab_bytes(const Geom &g) {
+    return me_bits8_table_words(g) * 4 + (size_t)g.H * g.nbx * kBits8M * 4 + 256;
+}
 inline size_t me_bits8_cpl_bytes(const Geom &g, int n) { return (size_t)n * g.N * kBits8Blk * 4; }
 inline int me_bits8_cur_wgs(const Geom &g) {   // workgroups of k_bits_cur8 per frame (a multiple of 8)
     return 8 * (((g.N + kBits8CurBlocks - 1) / kBits8CurBlocks + 7) / 8);
@@ -326,15 +367,16 @@ inline bool me_bits8_worthwhile(const Geom &g, int n) {
 }
 inline int me_bits8_groups(int n) { return (n + kBits8NF - 1) / kBits8NF; }
 
-inline void launch_bits_ref8(const Geom &g, hipStream_t stream, const uint8_t *ref, size_t ref_bytes, uint32_t *rtab) {
+inline void launch_bits_ref8(const Geom &g, hipStream_t stream, const uint8_t *ref, size_t ref_bytes, uint32_t *rtab,
+                             uint32_t *r2 = nullptr) {
     const uint32_t total = (uint32_t)g.H * (uint32_t)g.nbx * kBits8M;
-    hipLaunchKernelGGL(k_bits_ref8, dim3((total + 255) / 256), dim3(256), 0, stream, ref, (uint32_t)ref_bytes, g, rtab);
+    hipLaunchKernelGGL(k_bits_ref8, dim3((total + 255) / 256), dim3(256), 0, stream, ref, (uint32_t)ref_bytes, g, rtab, r2);
 }
 inline void launch_bits_cur8(const Geom &g, hipStream_t stream, const uint8_t *curs, size_t stride, const uint8_t *ref,
-                             int n, uint32_t *cpl, uint2 *binfo, uint32_t *ns_part, hipEvent_t ev_start = nullptr,
-                             hipEvent_t ev_stop = nullptr) {
+                             int n, uint32_t *cpl, uint2 *binfo, uint32_t *ns_part, const uint32_t *r2 = nullptr,
+                             uint32_t *sums = nullptr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     hipExtLaunchKernelGGL(k_bits_cur8, dim3(me_bits8_cur_wgs(g) * n), dim3(256), 0, stream, ev_start, ev_stop, 0, curs,
-                          stride, ref, g, n, cpl, binfo, ns_part);
+                          stride, ref, g, n, cpl, binfo, ns_part, r2, sums);
 }
 inline void launch_bits_search8(const Geom &g, hipStream_t stream, const uint32_t *rtab, const uint32_t *cpl,
                                 const uint2 *binfo, const uint32_t *sums, int n, int16_t *mv, const uint32_t *ns_part,

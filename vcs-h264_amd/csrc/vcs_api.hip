@@ -281,8 +281,9 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     // not part of VCS_T_ME, which times the search kernel alone
     // (the one-band bit-plane search makes the 16x16 table itself, from k_bits_ref's row-pair sums)
     const bool fold_sums = bits && !c->sums_valid && me_bits_bands(c->g) == 1;
-    if (fold_sums) c->rtab_valid = false;
-    if (!c->sums_valid && !fold_sums && !force_generic && (c->me_fast_ok || c->me_fast8_ok)) {
+    const bool fold_sums8 = bits8 && !c->sums_valid;   // the same at 8x8 (k_bits_ref8's chunk sums)
+    if (fold_sums || fold_sums8) c->rtab_valid = false;
+    if (!c->sums_valid && !fold_sums && !fold_sums8 && !force_generic && (c->me_fast_ok || c->me_fast8_ok)) {
         if (c->me_fast_ok) launch_me_fast_sums(c->g, c->stream, c->cus, ref, c->d_sums);
         else launch_me_fast8_sums(c->g, c->stream, c->cus, ref, c->d_sums);
         HIP_TRY(c, hipGetLastError());
@@ -341,16 +342,19 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
     if (bits8) {   // the 8x8 bit-plane search (me_bits8.hpp): chunk table per reference, planes, search
         int rc = ensure_bits(c, n);
         if (rc) return rc;
+        uint32_t *r2 = c->d_rtab + me_bits8_table_words(c->g);   // chunk sums behind the chunk table
         if (!c->rtab_valid) {
-            launch_bits_ref8(c->g, c->stream, ref, c->Fs + me_fast_ref_slack(c->g), c->d_rtab);
+            launch_bits_ref8(c->g, c->stream, ref, c->Fs + me_fast_ref_slack(c->g), c->d_rtab, r2);
             HIP_TRY(c, hipGetLastError());
             c->rtab_valid = true;
         }
         uint32_t *ns_part = (uint32_t *)(c->d_binfo + (size_t)n * c->g.N);
         EvPair evp, ev;
         if ((rc = t_begin(c, VCS_T_ME_PREP, &evp, /*attach=*/true))) return rc;
-        launch_bits_cur8(c->g, c->stream, curs, stride, ref, n, c->d_cpl, c->d_binfo, ns_part, evp.a, evp.b);
+        launch_bits_cur8(c->g, c->stream, curs, stride, ref, n, c->d_cpl, c->d_binfo, ns_part,
+                         fold_sums8 ? r2 : nullptr, c->d_sums, evp.a, evp.b);
         if ((rc = t_end(c, &evp))) return rc;
+        if (fold_sums8) c->sums_valid = true;
         static const bool pf_tail_wgs = [] { const char *e = getenv("VCS_BITS_PF"); return !(e && e[0] == '0'); }();
         const bool pf = c->pf_in_search && pf_tail_wgs && (size_t)n * stride < 0xFFFFFFFFull;
         c->pf_in_search = pf;
