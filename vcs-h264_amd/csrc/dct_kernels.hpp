@@ -23,9 +23,12 @@ namespace vcs {
 constexpr int kTilePad = 72;  // doubles per tile in the LDS transpose buffer
 constexpr int kOutPad = 9;    // elements per output row in the LDS store buffer (8 + 1 pad)
 #ifndef VCS_FDCT_WAVES
-#define VCS_FDCT_WAVES 4
+#define VCS_FDCT_WAVES 8
 #endif
-constexpr int kFdctWaves = VCS_FDCT_WAVES;  // strips (waves) per k_fdct workgroup
+// strips (waves) per k_fdct workgroup: eight adjacent strips on one CU (4 KB of every plane row in a run,
+// shared pixel lines through one L1).  Round 3, 2-D grid: 4 / 6 / 8 / 10 / 12 waves = 0.288 / 0.278 / 0.275 /
+// 0.279 / 0.277 ms per 29 x 1080p (round 2, 1-D grid: 1 / 2 / 4 / 8 = 0.300 / 0.286 / 0.288 / 0.282).
+constexpr int kFdctWaves = VCS_FDCT_WAVES;
 #ifndef VCS_IDCT_WAVES
 #define VCS_IDCT_WAVES 4
 #endif
