@@ -123,14 +123,18 @@ __global__ __launch_bounds__(256) void k_bits_ref(const uint8_t *__restrict__ re
 // 16-byte pieces, the co-located reference pieces for the static test, three 32-byte
 // transposes, 96 contiguous bytes out (a workgroup = 32 blocks = 24 KB of planes in one
 // run).  The block sums meet in the 8 lanes of a block by DPP.
-constexpr int kBitsCurBlocks = 32;
-__global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ curs, size_t cur_stride,
+#ifndef VCS_BITS_CUR_BLOCKS
+#define VCS_BITS_CUR_BLOCKS 32
+#endif
+constexpr int kBitsCurBlocks = VCS_BITS_CUR_BLOCKS;     // blocks per workgroup (8 threads each): 16 / 32 / 64 / 128 = 0.097 / 0.095 / 0.097 / 0.103 ms
+constexpr int kBitsCurThreads = kBitsCurBlocks * 8;
+__global__ __launch_bounds__(kBitsCurThreads) void k_bits_cur(const uint8_t *__restrict__ curs, size_t cur_stride,
                                                   const uint8_t *__restrict__ ref, Geom g, int n_frames,
                                                   uint32_t *__restrict__ cpl, uint2 *__restrict__ binfo,
                                                   uint32_t *__restrict__ ns_part, const uint32_t *__restrict__ r2,
                                                   uint32_t *__restrict__ sums) {
     __shared__ uint32_t s_ns;
-    __shared__ uint4 s_out[4 * 384];
+    __shared__ uint4 s_out[kBitsCurThreads / 64 * 384];
     const int tid = threadIdx.x, p = tid & 7;
     // workgroups go round-robin to the 8 XCDs: XCD x takes the x-th eighth of every frame's blocks,
     // frame after frame, so that its band of the reference (0.8 MB at 1080p) stays in its L2 while
@@ -218,8 +222,8 @@ __global__ __launch_bounds__(256) void k_bits_cur(const uint8_t *__restrict__ cu
         constexpr int BS = 16, WIN = 32, STEP = 5;
         const size_t rw = (size_t)g.nbx * kBitsM;   // r2 words per picture row
 #pragma unroll 1
-        for (int it = 0; it < kBitsCurBlocks * kMe16SumStride / 256; it++) {
-            const int e = tid + 256 * it, bi = e / kMe16SumStride, cand = e - bi * kMe16SumStride;
+        for (int it = 0; it < kBitsCurBlocks * kMe16SumStride / kBitsCurThreads; it++) {
+            const int e = tid + kBitsCurThreads * it, bi = e / kMe16SumStride, cand = e - bi * kMe16SumStride;
             const int b = blockIdx_blk0 + bi;
             if (b >= g.N) continue;
             const int by = b / g.nbx, bx = b - by * g.nbx;
@@ -620,7 +624,7 @@ inline size_t me_bits_rtab_bytes(const Geom &g) {
 }
 inline size_t me_bits_cpl_bytes(const Geom &g, int n) { return (size_t)n * g.N * kBitsBlk * 4; }
 inline size_t me_bits_binfo_bytes(const Geom &g, int n) {   // {static-test sum, sum(c)} per block + the static counts per workgroup
-    return (size_t)n * g.N * sizeof(uint2) + (size_t)n * (8 * (((g.N + 31) / 32 + 7) / 8)) * sizeof(uint32_t);
+    return (size_t)n * g.N * sizeof(uint2) + (size_t)n * (8 * (((g.N + kBitsCurBlocks - 1) / kBitsCurBlocks + 7) / 8)) * sizeof(uint32_t);
 }
 
 // VCS_ME16_BITS: 0 = off (k_me16g / k_me16r / k_me16), 1 = default (batches of >= kBitsMinFrames
@@ -662,7 +666,7 @@ inline int me_bits_cur_wgs(const Geom &g) {   // workgroups of k_bits_cur per fr
 inline void launch_bits_cur(const Geom &g, hipStream_t stream, const uint8_t *curs, size_t stride, const uint8_t *ref,
                             int n, uint32_t *cpl, uint2 *binfo, uint32_t *ns_part, const uint32_t *r2 = nullptr,
                             uint32_t *sums = nullptr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-    hipExtLaunchKernelGGL(k_bits_cur, dim3(me_bits_cur_wgs(g) * n), dim3(256), 0, stream, ev_start, ev_stop, 0, curs,
+    hipExtLaunchKernelGGL(k_bits_cur, dim3(me_bits_cur_wgs(g) * n), dim3(kBitsCurThreads), 0, stream, ev_start, ev_stop, 0, curs,
                           stride, ref, g, n, cpl, binfo, ns_part, r2, sums);
 }
 inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t *rtab, const uint32_t *cpl,
