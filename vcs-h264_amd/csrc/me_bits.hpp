@@ -303,8 +303,13 @@ struct BitsLds {
     static constexpr int kPlanes = 8 * NF * 96, kPart = ((NF + 1) / 2) * 40 * 4, kWave = kPlanes + kPart;
 };
 
+#ifndef VCS_BITS_WPW
+#define VCS_BITS_WPW 4
+#endif
+constexpr int kBitsWpw = VCS_BITS_WPW;   // waves (units) per k_me16b workgroup: 4 = the frame groups of one block position when ngroups = 4
+                                         // (2 / 4 / 8: search 0.243 / 0.243 / 0.269 ms -- two positions per workgroup live too long)
 template <int NF>
-__global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab, const uint32_t *__restrict__ cpl,
+__global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(const uint32_t *__restrict__ rtab, const uint32_t *__restrict__ cpl,
                                                const uint2 *__restrict__ binfo, const uint32_t *__restrict__ sums,
                                                Geom g, int n_frames, int ngroups, int16_t *__restrict__ mv,
                                                unsigned long long *__restrict__ cost_out,
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
 #ifndef VCS_EXP_BITS_LDSPAD
 #define VCS_EXP_BITS_LDSPAD 0   // experiment builds: extra LDS per workgroup (fewer workgroups per CU)
 #endif
-    __shared__ __attribute__((aligned(16))) uint8_t s_lds[4 * L::kWave + VCS_EXP_BITS_LDSPAD];
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kBitsWpw * L::kWave + VCS_EXP_BITS_LDSPAD];
     // clk_out (timing on): shader-clock cycles and 100 MHz ticks this workgroup lived, summed over
     // the workgroups: their quotient is the clock the chip held under this load
     const unsigned long long clk0 = clk_out ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -346,8 +351,8 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
         }
     }
     if (is_pf) {
-        const uint32_t nw = (uint32_t)pf_octets * 32u;
-        const uint32_t w = ((uint32_t)oct * 8u + (blockIdx.x & 7u)) * 4u + (uint32_t)wave;
+        const uint32_t nw = (uint32_t)pf_octets * 8u * (uint32_t)kBitsWpw;
+        const uint32_t w = ((uint32_t)oct * 8u + (blockIdx.x & 7u)) * (uint32_t)kBitsWpw + (uint32_t)wave;
         const __amdgpu_buffer_rsrc_t r_pf = buf_rsrc(pf_base, pf_total16 << 4);
         uint32_t it = 0;
         for (uint32_t i = w * 64u; i < pf_total16; i += nw * 64u, it++) {   // uniform trip count
@@ -368,9 +373,9 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
     // XCD's L2; nothing is shared between columns, so interleaving the columns costs no reuse and
     // keeps the XCDs equally busy when a region of the picture is static)
     const int per_col = g.nby * ngroups;
-    const int chunk = (((na + 7) / 8) * per_col + 3) & ~3;   // units per XCD (the XCDs with one column less idle at the end)
+    const int chunk = (((na + 7) / 8) * per_col + kBitsWpw - 1) / kBitsWpw * kBitsWpw;   // units per XCD (the XCDs with one column less idle at the end)
     if (blockIdx.x == 0 && a0 == 0) {   // static blocks per frame: the sums of k_bits_cur's per-workgroup counts
-        for (int f = wave; f < n_frames; f += 4) {
+        for (int f = wave; f < n_frames; f += kBitsWpw) {
             uint32_t v = 0;
             for (int i = lane; i < ns_per_frame; i += 64) v += ns_part[(size_t)f * ns_per_frame + i];
             v = wave_sum_u32(v);
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256) void k_me16b(const uint32_t *__restrict__ rtab
         }
     }
     const int xcd = blockIdx.x & 7, wg = oct;
-    const int ul = wg * 4 + wave;
+    const int ul = wg * kBitsWpw + wave;
     const int lc = (int)div_magic((uint32_t)ul, per_col_magic), bl = lc * 8 + xcd;   // bl: column inside the band
     if (ul < chunk && bl < na) {
         const int rem = ul - lc * per_col;
@@ -675,8 +680,8 @@ inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t
                                const uint8_t *pf_base = nullptr, size_t pf_bytes = 0, hipEvent_t ev_start = nullptr,
                                hipEvent_t ev_stop = nullptr) {
     const int ngroups = me_bits_groups(n);
-    const int chunk = (((na + 7) / 8) * g.nby * ngroups + 3) & ~3;   // units per XCD (k_me16b)
-    const int nsearch = 8 * (chunk / 4);
+    const int chunk = (((na + 7) / 8) * g.nby * ngroups + kBitsWpw - 1) / kBitsWpw * kBitsWpw;   // units per XCD (k_me16b)
+    const int nsearch = 8 * (chunk / kBitsWpw);
     // prefetch workgroups: octets interleaved 1 : ratio with the last search octets (VCS_BITS_PF_WGS, VCS_BITS_PF_RATIO)
     static const int npf_env = [] { const char *e = getenv("VCS_BITS_PF_WGS"); return e ? atoi(e) : 0; }();
     static const int ratio_env = [] { const char *e = getenv("VCS_BITS_PF_RATIO"); return e ? atoi(e) : 0; }();
@@ -684,10 +689,10 @@ inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t
     // gone again -- 256 workgroups, 1 : 1 behind the last search octets: tail 0.295 ms; the last 19 %
     // of the launch (1 : 3, 512): 0.32; the last 60 %: 0.36 (= no prefetch)
     const int ratio = ratio_env > 0 ? ratio_env : 1;
-    int pf8 = pf_base ? (npf_env > 0 ? npf_env : 256) / 8 : 0;
+    int pf8 = pf_base ? (npf_env > 0 ? npf_env : 256 * 4 / kBitsWpw) / 8 : 0;   // 1,024 prefetch waves
     if (pf8 * ratio > nsearch / 8) pf8 = nsearch / 8 / ratio;
     if (pf8 == 0) pf_base = nullptr;
-    hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(nsearch + 8 * pf8), dim3(256), 0, stream, ev_start, ev_stop, 0,
+    hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(nsearch + 8 * pf8), dim3(64 * kBitsWpw), 0, stream, ev_start, ev_stop, 0,
                           rtab, cpl, binfo, sums, g, n, ngroups, mv, cost, clk, pf_base,
                           (uint32_t)(pf_base ? pf_bytes >> 4 : 0), nsearch, pf8, ratio, ns_part, me_bits_cur_wgs(g), ns,
                           a0, na, magic_u32((uint32_t)(g.nby * ngroups)), magic_u32((uint32_t)ngroups));
