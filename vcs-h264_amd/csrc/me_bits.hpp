@@ -687,9 +687,10 @@ inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t
     static const int ratio_env = [] { const char *e = getenv("VCS_BITS_PF_RATIO"); return e ? atoi(e) : 0; }();
     // measured (tools/gpu_pf_sweep.sh): lines prefetched more than ~30 us before the tail starts are
     // gone again -- 256 workgroups, 1 : 1 behind the last search octets: tail 0.295 ms; the last 19 %
-    // of the launch (1 : 3, 512): 0.32; the last 60 %: 0.36 (= no prefetch)
+    // of the launch (1 : 3, 512): 0.32; the last 60 %: 0.36 (= no prefetch).  Count, 1 : 1 (step, no
+    // events, 3 runs each): 256 / 384 / 512 / 768 / 1024 = 0.6433 / 0.6383 / 0.6439 / 0.6514 / 0.6749 ms.
     const int ratio = ratio_env > 0 ? ratio_env : 1;
-    int pf8 = pf_base ? (npf_env > 0 ? npf_env : 256 * 4 / kBitsWpw) / 8 : 0;   // 1,024 prefetch waves
+    int pf8 = pf_base ? (npf_env > 0 ? npf_env : 384 * 4 / kBitsWpw) / 8 : 0;   // 1,536 prefetch waves
     if (pf8 * ratio > nsearch / 8) pf8 = nsearch / 8 / ratio;
     if (pf8 == 0) pf_base = nullptr;
     hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(nsearch + 8 * pf8), dim3(64 * kBitsWpw), 0, stream, ev_start, ev_stop, 0,

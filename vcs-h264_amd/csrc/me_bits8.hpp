@@ -385,7 +385,8 @@ inline void launch_bits_search8(const Geom &g, hipStream_t stream, const uint32_
     const int ngroups = me_bits8_groups(n);
     const int chunk = (((g.nbx + 7) / 8) * g.nby * ngroups + 3) & ~3;   // units per XCD (k_me8b)
     const int nsearch = 8 * (chunk / 4);
-    const int npf = pf_base ? 256 : 0;   // prefetch workgroups behind the search's (k_me16b: why 256, why last)
+    static const int npf_env = [] { const char *e = getenv("VCS_BITS_PF_WGS"); return e ? atoi(e) & ~7 : 0; }();
+    const int npf = pf_base ? (npf_env > 0 ? npf_env : 384) : 0;   // prefetch workgroups behind the search's (k_me16b: why last; 128 / 256 / 384 / 512: step 0.632 / 0.622 / 0.6185 / 0.621 ms)
     hipExtLaunchKernelGGL((k_me8b<kBits8NF>), dim3(nsearch + npf), dim3(256), 0, stream, ev_start, ev_stop, 0, rtab, cpl,
                           binfo, sums, g, n, ngroups, mv, cost, pf_base, (uint32_t)(pf_base ? pf_bytes >> 4 : 0), nsearch,
                           ns_part, me_bits8_cur_wgs(g), ns, magic_u32((uint32_t)(g.nby * ngroups)), magic_u32((uint32_t)ngroups));
