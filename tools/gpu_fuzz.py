@@ -1,6 +1,7 @@
 """Randomised parity sweep of the batched motion search against the oracle (GPU box): random picture
 sizes (ragged edges included), block sizes 8 / 16, batch sizes 1..40, thresholds, and content from
-"every block moves" to "nearly everything static", with the bit-plane search forced on every launch
+"every block moves" to "nearly everything static" (a quarter of the batches also checks one frame's
+coefficient planes, another quarter one decoded frame), with the bit-plane search forced on every launch
 (VCS_ME16_BITS=2 VCS_ME8_BITS=2) or left to the default selection.
 usage: python tools/gpu_fuzz.py [--cases 120] [--seed 0] [--max-h 400] [--max-w 640]"""
 import argparse
@@ -55,10 +56,19 @@ for case in range(a.cases):
         c.set_params(sim_thresh=thresh)
         c.set_ref(ref)
         if batch:
-            c.gop_reserve(n)
+            dec = case % 4 == 1                  # a quarter of the cases also decode the batch
+            c.gop_reserve(n, with_decode=dec)
             c.gop_upload(0, frames)
             c.gop_encode(0, n)
             mv, ns = c.gop_get_mv(0, n)
+            if dec:                              # k_idct: one decoded frame against the oracle's decoder
+                c.gop_decode(0, n)
+                k = int(rng.integers(0, n))
+                omv, _ = oracle.me(frames[k], ref, bs, thresh=thresh)
+                _, oplanes, _ = oracle.encode_p(frames[k], ref, bs, thresh=thresh)
+                if not np.array_equal(c.gop_get_decoded(k), oracle.decode_p(omv, oplanes, ref, bs)):
+                    print("DECODE MISMATCH case %d frame %d: H %d W %d bs %d n %d thresh %d kind %d" % (case, k, H, W, bs, n, thresh, kind), flush=True)
+                    bad += 1
             if case % 4 == 0:                    # the tail behind the search: one frame's coefficient planes
                 k = int(rng.integers(0, n))
                 _, oplanes, _ = oracle.encode_p(frames[k], ref, bs, thresh=thresh)
