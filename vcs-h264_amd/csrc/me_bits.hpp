@@ -128,96 +128,127 @@ __global__ __launch_bounds__(256) void k_bits_ref(const uint8_t *__restrict__ re
 #endif
 constexpr int kBitsCurBlocks = VCS_BITS_CUR_BLOCKS;     // blocks per workgroup (8 threads each): 16 / 32 / 64 / 128 = 0.097 / 0.095 / 0.097 / 0.103 ms
 constexpr int kBitsCurThreads = kBitsCurBlocks * 8;
+#ifndef VCS_BITS_CUR_FPT
+#define VCS_BITS_CUR_FPT 4
+#endif
+// frames per thread: a thread keeps its co-located reference pieces (and their byte sum) in registers for
+// kBitsCurFpt frames of the batch -- read per frame they are L2 hits, but half of the kernel's loads
+// (0.022 of its 0.064 ms at 29 x 1080p, VCS_EXP_BITS_NOREF)
+constexpr int kBitsCurFpt = VCS_BITS_CUR_FPT;
 __global__ __launch_bounds__(kBitsCurThreads) void k_bits_cur(const uint8_t *__restrict__ curs, size_t cur_stride,
                                                   const uint8_t *__restrict__ ref, Geom g, int n_frames,
                                                   uint32_t *__restrict__ cpl, uint2 *__restrict__ binfo,
                                                   uint32_t *__restrict__ ns_part, const uint32_t *__restrict__ r2,
                                                   uint32_t *__restrict__ sums) {
-    __shared__ uint32_t s_ns;
+    __shared__ uint32_t s_ns[kBitsCurFpt];
     __shared__ uint4 s_out[kBitsCurThreads / 64 * 384];
     const int tid = threadIdx.x, p = tid & 7;
     // workgroups go round-robin to the 8 XCDs: XCD x takes the x-th eighth of every frame's blocks,
-    // frame after frame, so that its band of the reference (0.8 MB at 1080p) stays in its L2 while
-    // the frames stream through -- fetched anew per frame the co-located reference pieces are a
-    // third of the kernel's fabric traffic
-    const int per = (int)(gridDim.x >> 3) / n_frames;            // workgroups per XCD and frame
+    // frame group after frame group, so that its band of the reference (0.8 MB at 1080p) stays in its L2
+    // while the frames stream through
+    const int nfg = (n_frames + kBitsCurFpt - 1) / kBitsCurFpt;   // frame groups
+    const int per = (int)(gridDim.x >> 3) / nfg;                   // workgroups per XCD and frame group
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int f = idx / per;
-    const int blockIdx_blk0 = (xcd * per + (idx - f * per)) * kBitsCurBlocks;
+    const int fg = idx / per, f_first = fg * kBitsCurFpt, nf = min(kBitsCurFpt, n_frames - f_first);
+    const int wg_in_frame = xcd * per + (idx - fg * per);
+    const int blockIdx_blk0 = wg_in_frame * kBitsCurBlocks;
     const int blk = blockIdx_blk0 + (tid >> 3);
-    if (tid == 0) s_ns = 0;
+    if (tid < kBitsCurFpt) s_ns[tid] = 0;
     __syncthreads();
     const uint32_t fbytes = (uint32_t)(g.H * g.pitch);
-    const __amdgpu_buffer_rsrc_t r_cur = buf_rsrc(curs + (size_t)f * cur_stride, fbytes);
     const __amdgpu_buffer_rsrc_t r_ref = buf_rsrc(ref, fbytes);
     const int blkc = min(blk, g.N - 1);
     const int byi = blkc / g.nbx, bxi = blkc - byi * g.nbx;
     const uint32_t o = (uint32_t)((byi * 16 + 2 * p) * g.pitch + 48 * bxi);
-    uint4 vc[6], vr[6];
+    uint32_t oi[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) oi[i] = o + (i >= 3 ? (uint32_t)g.pitch + 16u * (i - 3) : 16u * i);
+    uint4 vr[6], vc[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) vr[i] = buf_ld128(r_ref, oi[i], 0);
+    {
+        const __amdgpu_buffer_rsrc_t r_cur = buf_rsrc(curs + (size_t)f_first * cur_stride, fbytes);
+#pragma unroll
+        for (int i = 0; i < 6; i++) vc[i] = buf_ld128(r_cur, oi[i], 0);
+    }
+    uint32_t sr = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        const uint32_t oi = o + (i >= 3 ? (uint32_t)g.pitch + 16u * (i - 3) : 16u * i);
-        vc[i] = buf_ld128(r_cur, oi, 0);
-        vr[i] = buf_ld128(r_ref, oi, 0);
+        sr = __builtin_amdgcn_sad_u8(vr[i].x, 0u, sr); sr = __builtin_amdgcn_sad_u8(vr[i].y, 0u, sr);
+        sr = __builtin_amdgcn_sad_u8(vr[i].z, 0u, sr); sr = __builtin_amdgcn_sad_u8(vr[i].w, 0u, sr);
     }
-    uint32_t s[24], sad = 0, sr = 0, sc = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        s[4 * i] = vc[i].x; s[4 * i + 1] = vc[i].y; s[4 * i + 2] = vc[i].z; s[4 * i + 3] = vc[i].w;
-        const uint32_t r4[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            sad = __builtin_amdgcn_sad_u8(r4[e], s[4 * i + e], sad);
-            sr = __builtin_amdgcn_sad_u8(r4[e], 0u, sr);
-            sc = __builtin_amdgcn_sad_u8(s[4 * i + e], 0u, sc);
-        }
-    }
-    // sum(max(r - c, 0)) = (sum|r - c| + sum r - sum c) / 2, over the 8 row pairs of the block
-    uint32_t sd2 = sad + sr - sc;
-    sd2 += dpp_u32<0xB1>(sd2); sd2 += dpp_u32<0x4E>(sd2); sd2 += dpp_u32<0x141>(sd2);
-    sc += dpp_u32<0xB1>(sc); sc += dpp_u32<0x4E>(sc); sc += dpp_u32<0x141>(sc);
-    const uint32_t sdiff = sd2 >> 1;
-    // a thread's 96 bytes are contiguous in cpl and so are the wave's 6 KB; they leave through LDS so
-    // that one store instruction writes 1 KB in a row (16-byte pieces 96 bytes apart are partial-line
-    // writes: 0.097 -> 0.0xx ms)
     uint4 *const s_w = s_out + (tid >> 6) * 384;
     const int lane = tid & 63;
+    const bool head = p == 0 && blk < g.N;
+#pragma unroll 1
+    for (int ff = 0; ff < nf; ff++) {
+        const int f = f_first + ff;
+        uint4 vn[6];   // the next frame's pieces, requested before this frame's are worked on
+        if (ff + 1 < nf) {
+            const __amdgpu_buffer_rsrc_t r_nxt = buf_rsrc(curs + (size_t)(f + 1) * cur_stride, fbytes);
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-        uint32_t x[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = s[8 * d + i];
-        bits_transpose8(x);
-        s_w[lane * 6 + 2 * d] = make_uint4(x[0], x[1], x[2], x[3]);
-        s_w[lane * 6 + 2 * d + 1] = make_uint4(x[4], x[5], x[6], x[7]);
-    }
-    wave_lds_fence();
-    {
-        const int wblk0 = blockIdx_blk0 + (tid >> 6) * 8;   // first block of this wave
-        uint4 *dst = (uint4 *)(cpl + ((size_t)f * g.N + wblk0) * kBitsBlk);
+            for (int i = 0; i < 6; i++) vn[i] = buf_ld128(r_nxt, oi[i], 0);
+        }
+        uint32_t s[24], sad = 0, sc = 0;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            const int e = i * 64 + lane;                      // 16-byte piece of the wave's 8 blocks x 48 pieces
-            // (non-temporal: the planes are read back once, 0.1 ms later, by kernels with bandwidth to
-            // spare; step -0.9 % in 4 of 4 A/B pairs)
-            if (wblk0 + e / 48 < g.N) __builtin_nontemporal_store(*(const u32x4_t *)&s_w[e], (u32x4_t *)&dst[e]);
+            s[4 * i] = vc[i].x; s[4 * i + 1] = vc[i].y; s[4 * i + 2] = vc[i].z; s[4 * i + 3] = vc[i].w;
+            const uint32_t r4[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                sad = __builtin_amdgcn_sad_u8(r4[e], s[4 * i + e], sad);
+                sc = __builtin_amdgcn_sad_u8(s[4 * i + e], 0u, sc);
+            }
+        }
+        // sum(max(r - c, 0)) = (sum|r - c| + sum r - sum c) / 2, over the 8 row pairs of the block
+        uint32_t sd2 = sad + sr - sc;
+        sd2 += dpp_u32<0xB1>(sd2); sd2 += dpp_u32<0x4E>(sd2); sd2 += dpp_u32<0x141>(sd2);
+        sc += dpp_u32<0xB1>(sc); sc += dpp_u32<0x4E>(sc); sc += dpp_u32<0x141>(sc);
+        const uint32_t sdiff = sd2 >> 1;
+        // a thread's 96 bytes are contiguous in cpl and so are the wave's 6 KB; they leave through LDS so
+        // that one store instruction writes 1 KB in a row (16-byte pieces 96 bytes apart are partial-line
+        // writes: 0.097 -> 0.085 ms)
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            uint32_t x[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = s[8 * d + i];
+            bits_transpose8(x);
+            s_w[lane * 6 + 2 * d] = make_uint4(x[0], x[1], x[2], x[3]);
+            s_w[lane * 6 + 2 * d + 1] = make_uint4(x[4], x[5], x[6], x[7]);
+        }
+        wave_lds_fence();
+        {
+            const int wblk0 = blockIdx_blk0 + (tid >> 6) * 8;   // first block of this wave
+            uint4 *dst = (uint4 *)(cpl + ((size_t)f * g.N + wblk0) * kBitsBlk);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const int e = i * 64 + lane;                      // 16-byte piece of the wave's 8 blocks x 48 pieces
+                // (non-temporal: the planes are read back once, 0.1 ms later, by kernels with bandwidth to
+                // spare; step -0.9 % in 4 of 4 A/B pairs)
+                if (wblk0 + e / 48 < g.N) __builtin_nontemporal_store(*(const u32x4_t *)&s_w[e], (u32x4_t *)&dst[e]);
+            }
+        }
+        wave_lds_fence();   // the next frame rewrites the wave's staging area
+        if (head) binfo[(size_t)f * g.N + blk] = make_uint2(sdiff, sc);
+        const unsigned long long st = __ballot(head && !g.never_static && sdiff <= g.thresh);
+        if ((tid & 63) == 0 && st) atomicAdd(&s_ns[ff], (uint32_t)__builtin_popcountll(st));
+        if (ff + 1 < nf) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) vc[i] = vn[i];
         }
     }
-    const bool head = p == 0 && blk < g.N;
-    if (head) binfo[(size_t)f * g.N + blk] = make_uint2(sdiff, sc);
-    const unsigned long long st = __ballot(head && !g.never_static && sdiff <= g.thresh);
-    if ((tid & 63) == 0 && st) atomicAdd(&s_ns, (uint32_t)__builtin_popcountll(st));
     __syncthreads();
-    // static blocks of this workgroup; k_me16b adds the 8 * per counts of a frame up (no counter to
-    // zero before the launch, no atomics on it)
-    if (tid == 0) ns_part[(size_t)f * (8 * per) + xcd * per + (idx - f * per)] = s_ns;
+    // static blocks of this workgroup per frame; k_me16b adds the 8 * per counts of a frame up (no counter
+    // to zero before the launch, no atomics on it)
+    if (tid < nf) ns_part[(size_t)(f_first + tid) * (8 * per) + wg_in_frame] = s_ns[tid];
     // The sum(r) table of a new reference (what k_me16_sums makes: sums[blk * 128 + cand] = byte sum of
     // the candidate's 16 x 48 bytes, 0 for slots without a candidate), by the workgroups of the first
     // frame: a candidate's sum = 8 row-pair sums of k_bits_ref (r2 != null: the table is due).
 #ifdef VCS_EXP_BITS_NOFOLD   // experiment builds only (results are wrong): what the folded sum(r) table costs
     if (false) {
 #else
-    if (r2 && f == 0) {
+    if (r2 && fg == 0) {
 #endif
         constexpr int BS = 16, WIN = 32, STEP = 5;
         const size_t rw = (size_t)g.nbx * kBitsM;   // r2 words per picture row
@@ -671,7 +702,7 @@ inline int me_bits_cur_wgs(const Geom &g) {   // workgroups of k_bits_cur per fr
 inline void launch_bits_cur(const Geom &g, hipStream_t stream, const uint8_t *curs, size_t stride, const uint8_t *ref,
                             int n, uint32_t *cpl, uint2 *binfo, uint32_t *ns_part, const uint32_t *r2 = nullptr,
                             uint32_t *sums = nullptr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-    hipExtLaunchKernelGGL(k_bits_cur, dim3(me_bits_cur_wgs(g) * n), dim3(kBitsCurThreads), 0, stream, ev_start, ev_stop, 0, curs,
+    hipExtLaunchKernelGGL(k_bits_cur, dim3(me_bits_cur_wgs(g) * ((n + kBitsCurFpt - 1) / kBitsCurFpt)), dim3(kBitsCurThreads), 0, stream, ev_start, ev_stop, 0, curs,
                           stride, ref, g, n, cpl, binfo, ns_part, r2, sums);
 }
 inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t *rtab, const uint32_t *cpl,
