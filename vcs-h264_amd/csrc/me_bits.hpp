@@ -295,20 +295,6 @@ __device__ __forceinline__ uint32_t bits_count_lt(const uint32_t (&r)[kBitsT], c
     }
     return n;
 }
-// the same with the first step of the first chain already taken (b0): the search kernel puts its
-// next loads between that step and the rest
-__device__ __forceinline__ uint32_t bits_count_lt_from(const uint32_t (&r)[kBitsT], const uint32_t (&c)[kBitsT],
-                                                      uint32_t b0, uint32_t n) {
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        uint32_t b = d == 0 ? b0 : 0u;
-#pragma unroll
-        for (int k = d == 0 ? 1 : 0; k < 8; k++) b = bits_lt_step(r[8 * d + k], c[8 * d + k], b);
-        n = (uint32_t)__builtin_popcount(b) + n;
-        asm volatile("" : "+v"(n));
-    }
-    return n;
-}
 __device__ __forceinline__ void bits_ld_chunk(uint32_t (&r)[kBitsT], const uint32_t *__restrict__ rp) {
 #pragma unroll
     for (int q = 0; q < 6; q++) {
@@ -316,10 +302,56 @@ __device__ __forceinline__ void bits_ld_chunk(uint32_t (&r)[kBitsT], const uint3
         r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
     }
 }
+// the same through a buffer resource: 32-bit lane offset (bytes), no 64-bit address arithmetic per load
+__device__ __forceinline__ void bits_ld_chunk_buf(uint32_t (&r)[kBitsT], __amdgpu_buffer_rsrc_t rs, uint32_t off) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const uint4 v = buf_ld128(rs, off + (uint32_t)q * (kBitsM * 16), 0);
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+}
+
+// ---- the planes of one (frame, row pair) in 24 SGPRs, requested and collected BY HAND -----------
+// hipcc waits for every outstanding scalar load before the first use of any of them (scalar loads
+// return out of order, lgkmcnt is only exact at 0), so loads it knows about cannot be software-
+// pipelined.  These two statements hide the load from it: splanes_issue requests the 96 bytes
+// (s_load_dwordx16 + x8) and returns at once -- the registers are NOT valid yet --, splanes_wait is
+// the s_waitcnt and, through its "+s" operands, the only path from the request to a use.  Between
+// the two nothing may touch the registers (no copy, no spill): tools/check_smem_pipeline.py reads
+// the compiler's assembly and fails the build if anything does.
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p) {   // a wave-uniform pointer the compiler may hold for divergent: into SGPRs
+    const unsigned long long v = (unsigned long long)p;
+    return (T *)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+}
+typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+struct SPlanes { u32x16_t lo; u32x8_t hi; };
+__device__ __forceinline__ void splanes_issue(SPlanes &x, const uint32_t *base, uint32_t off) {   // off: bytes
+    asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx8 %1, %2, %4"
+                 : "=&s"(x.lo), "=&s"(x.hi) : "s"(base), "s"(off), "s"(off + 64u));
+}
+__device__ __forceinline__ void splanes_wait(SPlanes &x) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x.lo), "+s"(x.hi));
+}
+// #{r < c} over one chunk with the planes in SGPRs
+__device__ __forceinline__ uint32_t bits_count_lt_s(const uint32_t (&r)[kBitsT], const SPlanes &c, uint32_t n) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        uint32_t b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int t = 8 * d + k;
+            b = bits_lt_step(r[t], t < 16 ? c.lo[t] : c.hi[t - 16], b);
+        }
+        n = (uint32_t)__builtin_popcount(b) + n;
+        asm volatile("" : "+v"(n));
+    }
+    return n;
+}
 
 // frames [f0, f0 + nf) of group `grp` when n frames are dealt to `ngroups` waves as evenly as possible
-// (dealing them in pairs -- 29 -> 8, 8, 8, 5, two pair comparisons fewer per candidate than 8, 7, 7, 7
-// -- measures the same: a workgroup lives as long as its longest wave either way)
 __device__ __forceinline__ void bits_group(int n, int ngroups, uint32_t ngroups_magic, int grp, int &f0, int &nf) {
     const int q = (int)div_magic((uint32_t)n, ngroups_magic), r = n - q * ngroups;
     f0 = grp * q + min(grp, r);
@@ -328,7 +360,8 @@ __device__ __forceinline__ void bits_group(int n, int ngroups, uint32_t ngroups_
 
 // LDS of one wave: the planes of its NF current blocks, [row pair][frame][96 bytes] (filled by
 // LDS-direct loads, one per row pair), and the second pass's counts, [frame pair][40] (two 16-bit
-// counts per word: a count is at most 768) -- 6,784 bytes at NF = 8: six workgroups per CU
+// counts per word: a count is at most 768) -- 6,784 bytes at NF = 8: six workgroups per CU.  The
+// arg-min reuses the planes' area ([frame][64 lanes] keys, NF * 256 bytes).
 template <int NF>
 struct BitsLds {
     static constexpr int kPlanes = 8 * NF * 96, kPart = ((NF + 1) / 2) * 40 * 4, kWave = kPlanes + kPart;
@@ -339,29 +372,89 @@ struct BitsLds {
 #endif
 constexpr int kBitsWpw = VCS_BITS_WPW;   // waves (units) per k_me16b workgroup: 4 = the frame groups of one block position when ngroups = 4
                                          // (2 / 4 / 8: search 0.243 / 0.243 / 0.269 ms -- two positions per workgroup live too long)
-template <int NF>
-__global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(const uint32_t *__restrict__ rtab, const uint32_t *__restrict__ cpl,
-                                               const uint2 *__restrict__ binfo, const uint32_t *__restrict__ sums,
-                                               Geom g, int n_frames, int ngroups, int16_t *__restrict__ mv,
-                                               unsigned long long *__restrict__ cost_out,
-                                               unsigned long long *__restrict__ clk_out,
-                                               const uint8_t *__restrict__ pf_base, uint32_t pf_total16,
-                                               int n_search_wgs, int pf_octets, int pf_ratio,
-                                               const uint32_t *__restrict__ ns_part, int ns_per_frame,
-                                               uint32_t *__restrict__ n_static, int a0, int na,
-                                               uint32_t per_col_magic, uint32_t ngroups_magic) {
-    // (per_col_magic, ngroups_magic: magic_u32 of nby * ngroups and of ngroups -- the unit decode below
-    // is scalar, and a scalar division by a runtime value is a 25-instruction vector sequence)
+
+// The kernel's arguments travel as ONE struct, and the kernel reads them where it needs them through
+// the kernarg pointer made opaque (bits_args_again): after the first pass, whose 48 plane registers
+// leave the compiler ~50 scalar registers, everything is loaded and derived AGAIN instead of being
+// kept -- kept, hipcc spilled ~50 scalars to vector lanes around the loops (v_writelane / v_readlane
+// are vector instructions, in a kernel bound by vector issue; scalar loads and scalar arithmetic are
+// not).  Round 3's build: 156 lane moves per wave.
+struct BitsArgs {
+    const uint32_t *rtab, *cpl;
+    const uint2 *binfo;
+    const uint32_t *sums;
+    int16_t *mv;
+    unsigned long long *cost_out, *clk_out;
+    const uint8_t *pf_base;
+    const uint32_t *ns_part;
+    uint32_t *n_static;
+    int H, W, N, nbx, nby;
+    uint32_t thresh;
+    int never_static, n_frames, ngroups;
+    uint32_t pf_total16;
+    int n_search_wgs, pf_octets, pf_ratio, ns_per_frame, a0, na;
+    uint32_t per_col_magic, ngroups_magic;   // magic_u32 of nby * ngroups and of ngroups: the unit decode is scalar,
+                                             // and a scalar division by a runtime value is a 25-instruction vector sequence
+};
+typedef const __attribute__((address_space(4))) BitsArgs *BitsArgsP;
+__device__ __forceinline__ BitsArgsP bits_args() { return (BitsArgsP)__builtin_amdgcn_kernarg_segment_ptr(); }
+__device__ __forceinline__ BitsArgsP bits_args_again() {   // the same pointer, but nothing loaded through the old one is reused
+    BitsArgsP p = bits_args();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+// 65536 / n + 1 (x / n for x < 512, n <= 36, as a multiply and a shift): looked up, not divided
+__device__ __constant__ const uint32_t kBitsInv[40] = {
+    0, 65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4097, 3856, 3641, 3450,
+    3277, 3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2049, 1986, 1928, 1873, 1821, 1772, 1725, 1681};
+
+// what a wave needs to know about its unit (block position, frame group): all scalar
+struct BitsUnit {
+    int bl, blk, f0, nf, x, y, i_min, j_min, nci, ncj, ncand;
+    uint32_t inv_ncj;
+};
+__device__ __forceinline__ bool bits_unit(int ul, BitsArgsP A, int xcd, BitsUnit &u) {
     constexpr int BS = 16, WIN = 32, STEP = 5;
+    const int ngroups = A->ngroups, na = A->na;
+    const uint32_t ngroups_magic = A->ngroups_magic;
+    const int per_col = A->nby * ngroups;
+    const int chunk = (((na + 7) / 8) * per_col + kBitsWpw - 1) / kBitsWpw * kBitsWpw;   // units per XCD (the XCDs with one column less idle at the end)
+    const int lc = (int)div_magic((uint32_t)ul, A->per_col_magic);
+    u.bl = lc * 8 + xcd;   // column inside the band
+    if (!(ul < chunk && u.bl < na)) return false;
+    const int rem = ul - lc * per_col;
+    const int byi = (int)div_magic((uint32_t)rem, ngroups_magic), bxi = A->a0 + u.bl;
+    // the groups of a position differ in size (29 frames: 8, 7, 7, 7): rotated from position to
+    // position, so that the same wave slot (SIMD) does not get the large one every time (-0.4 % of
+    // the step in 3 of 3 A/B pairs)
+    const int gr = rem - byi * ngroups + byi;
+    const int grp = gr - ngroups * (int)div_magic((uint32_t)gr, ngroups_magic);
+    u.blk = byi * A->nbx + bxi;
+    bits_group(A->n_frames, ngroups, ngroups_magic, grp, u.f0, u.nf);
+    u.x = bxi * BS; u.y = byi * BS;
+    u.i_min = max(u.y - WIN, 0);
+    u.j_min = max(u.x - WIN, 0);
+    const int i_max = min(u.y + WIN, A->H), j_max = min(u.x + WIN, A->W);
+    const int ri = i_max - BS - u.i_min, rj = j_max - BS - u.j_min;
+    u.nci = ri >= 1 ? (ri - 1) / STEP + 1 : 0;
+    u.ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
+    u.ncand = u.nci * u.ncj;
+    u.inv_ncj = kBitsInv[u.ncj];   // cand / ncj for cand < 128, ncj <= 10
+    return true;
+}
+
+template <int NF>
+__global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value) {
+    constexpr int STEP = 5;
+    static_assert(NF % 4 == 0 && NF <= 8, "two plane buffers in turn; the split pass pairs frame f with f + NF / 2 in one counter word; NF * 6 lanes prefetch");
     using L = BitsLds<NF>;
-#ifndef VCS_EXP_BITS_LDSPAD
-#define VCS_EXP_BITS_LDSPAD 0   // experiment builds: extra LDS per workgroup (fewer workgroups per CU)
-#endif
-    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kBitsWpw * L::kWave + VCS_EXP_BITS_LDSPAD];
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[kBitsWpw * L::kWave];
+    const BitsArgsP A = bits_args();
     // clk_out (timing on): shader-clock cycles and 100 MHz ticks this workgroup lived, summed over
     // the workgroups: their quotient is the clock the chip held under this load
-    const unsigned long long clk0 = clk_out ? __builtin_amdgcn_s_memtime() : 0ull;
-    const unsigned long long rt0 = clk_out ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const bool clocked = A->clk_out != nullptr && threadIdx.x == 0 && (blockIdx.x & 63u) == 0;
+    const unsigned long long clk0 = clocked ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long rt0 = clocked ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Infinity Cache prefetch for the tail kernel (vcs_api.hip, k_l3_prefetch, explains why).  The
@@ -373,8 +466,9 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(const uint32_t *__restr
     // [pf_ratio search octets, 1 prefetch octet]
     int oct = (int)(blockIdx.x >> 3);
     bool is_pf = false;
-    if (pf_octets) {
-        const int head = n_search_wgs / 8 - pf_ratio * pf_octets;
+    if (A->pf_octets) {
+        const int pf_ratio = A->pf_ratio;
+        const int head = A->n_search_wgs / 8 - pf_ratio * A->pf_octets;
         if (oct >= head) {
             const int o2 = oct - head, grp = o2 / (pf_ratio + 1), r = o2 - grp * (pf_ratio + 1);
             is_pf = r == pf_ratio;
@@ -382,9 +476,10 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(const uint32_t *__restr
         }
     }
     if (is_pf) {
-        const uint32_t nw = (uint32_t)pf_octets * 8u * (uint32_t)kBitsWpw;
+        const uint32_t pf_total16 = A->pf_total16;
+        const uint32_t nw = (uint32_t)A->pf_octets * 8u * (uint32_t)kBitsWpw;
         const uint32_t w = ((uint32_t)oct * 8u + (blockIdx.x & 7u)) * (uint32_t)kBitsWpw + (uint32_t)wave;
-        const __amdgpu_buffer_rsrc_t r_pf = buf_rsrc(pf_base, pf_total16 << 4);
+        const __amdgpu_buffer_rsrc_t r_pf = buf_rsrc(A->pf_base, pf_total16 << 4);
         uint32_t it = 0;
         for (uint32_t i = w * 64u; i < pf_total16; i += nw * 64u, it++) {   // uniform trip count
             if (i + (uint32_t)lane < pf_total16)
@@ -403,225 +498,244 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(const uint32_t *__restr
     // walks down each of them (the chunk rows of vertically adjacent blocks overlap: they meet in the
     // XCD's L2; nothing is shared between columns, so interleaving the columns costs no reuse and
     // keeps the XCDs equally busy when a region of the picture is static)
-    const int per_col = g.nby * ngroups;
-    const int chunk = (((na + 7) / 8) * per_col + kBitsWpw - 1) / kBitsWpw * kBitsWpw;   // units per XCD (the XCDs with one column less idle at the end)
-    if (blockIdx.x == 0 && a0 == 0) {   // static blocks per frame: the sums of k_bits_cur's per-workgroup counts
-        for (int f = wave; f < n_frames; f += kBitsWpw) {
+    if (blockIdx.x == 0 && A->a0 == 0) {   // static blocks per frame: the sums of k_bits_cur's per-workgroup counts
+        const int ns_per_frame = A->ns_per_frame;
+        for (int f = wave; f < A->n_frames; f += kBitsWpw) {
             uint32_t v = 0;
-            for (int i = lane; i < ns_per_frame; i += 64) v += ns_part[(size_t)f * ns_per_frame + i];
+            for (int i = lane; i < ns_per_frame; i += 64) v += A->ns_part[(size_t)f * ns_per_frame + i];
             v = wave_sum_u32(v);
-            if (lane == 0) n_static[f] = v;
+            if (lane == 0) A->n_static[f] = v;
         }
     }
-    const int xcd = blockIdx.x & 7, wg = oct;
-    const int ul = wg * kBitsWpw + wave;
-    const int lc = (int)div_magic((uint32_t)ul, per_col_magic), bl = lc * 8 + xcd;   // bl: column inside the band
-    if (ul < chunk && bl < na) {
-        const int rem = ul - lc * per_col;
-        const int byi = (int)div_magic((uint32_t)rem, ngroups_magic), bxi = a0 + bl;
-        // the groups of a position differ in size (29 frames: 8, 7, 7, 7): rotated from position to
-        // position, so that the same wave slot (SIMD) does not get the large one every time (-0.4 % of
-        // the step in 3 of 3 A/B pairs)
-        const int gr = rem - byi * ngroups + byi;
-        const int grp = gr - ngroups * (int)div_magic((uint32_t)gr, ngroups_magic);
-        const int blk = byi * g.nbx + bxi;
-        int f0, nf;
-        bits_group(n_frames, ngroups, ngroups_magic, grp, f0, nf);
-        const int x = bxi * BS, y = byi * BS;
-        const int i_min = max(y - WIN, 0), i_max = min(y + WIN, g.H);
-        const int j_min = max(x - WIN, 0), j_max = min(x + WIN, g.W);
-        const int ri = i_max - BS - i_min, rj = j_max - BS - j_min;
-        const int nci = ri >= 1 ? (ri - 1) / STEP + 1 : 0;
-        const int ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
-        const int ncand = nci * ncj;
-        const uint32_t inv_ncj = ncj ? 65536u / (uint32_t)ncj + 1u : 0u;   // cand / ncj for cand < 128, ncj <= 10
+    const int xcd = blockIdx.x & 7;
+    int ul = oct * kBitsWpw + wave;
+    BitsUnit u;
+    if (bits_unit(ul, A, xcd, u)) {
+        // A wave's first loads -- the static-test records, the first chunk, the planes of the first two
+        // row pairs -- are all requested before the first of them is waited for: one round trip at the
+        // start of a wave instead of ten in a row (round 3 read the eight records by scalar loads, each
+        // behind a branch; they were written by another XCD's k_bits_cur, so every one misses L2:
+        // search -5.7 %).  The chunk and the planes are requested on spec: a wave whose frames all turn
+        // out static has loaded 8 KB for nothing.
+        // (All of these addresses are valid whatever the unit's geometry: row i_min of the table, frame
+        // f0 .. f0 + nf - 1 >= f0 of the planes and the records -- a group has at least one frame.)
+        // per frame: static?  Lane f reads frame f's record (read again at the end rather than kept)
+        const int N = A->N;
+        uint32_t sd = A->binfo[(size_t)(u.f0 + max(min(lane, u.nf - 1), 0)) * N + u.blk].x;
 
-        // per frame: static? (scalar; the records are read again at the end rather than kept: 16
-        // SGPRs the loops below would otherwise spill around)
-        uint32_t skip = 0;   // bit f: nothing to search for frame f0 + f
-#pragma unroll
-        for (int f = 0; f < NF; f++) {
-            if (f < nf) {
-                const uint32_t sd = binfo[(size_t)(f0 + f) * g.N + blk].x;
-                if (!g.never_static && sd <= g.thresh) skip |= 1u << f;
-            } else {
-                skip |= 1u << f;
-            }
-        }
+        const uint32_t wstride4 = (uint32_t)A->na * (kBitsWA * 4);   // bytes per window row of rtab (a band is at most 1 GiB)
+        const __amdgpu_buffer_rsrc_t r_t = buf_rsrc(A->rtab, 0xFFFFFFFFu);
+        const uint32_t *__restrict__ cblk = uniform_ptr(A->cpl + ((size_t)u.f0 * N + u.blk) * kBitsBlk);
+        const uint32_t cfs4 = (uint32_t)N * (kBitsBlk * 4);   // bytes per frame of cpl (a group spans < 4 GiB: me_bits_worthwhile)
+        // The planes of the wave's NF current blocks arrive by LDS-direct loads, one instruction
+        // per row pair (lane = (frame, 16-byte piece)), two rounds ahead of their use.  They are
+        // read twice: by the first pass through s_load from L2 -- a scalar load that misses L2
+        // takes ~2,000 cycles and a wave has one in flight; the LDS-direct load is what brings the
+        // line into L2 in time (measured: 0.49 ms without, 0.22 ms with every plane load hitting)
+        // -- and by the second pass from LDS.
+        const __amdgpu_buffer_rsrc_t r_c = buf_rsrc(cblk, 0xFFFFFFFFu);
+        const uint32_t pf_fr = (uint32_t)max(min(lane / 6, u.nf - 1), 0);
+        const uint32_t pf_off = pf_fr * cfs4 + 16u * (uint32_t)(lane - (lane / 6) * 6);
+        auto prefetch = [&](int p) {
+            if (lane < NF * 6)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    r_c, (__attribute__((address_space(3))) void *)(s_c + p * (NF * 96)), 16,
+                    (int)(pf_off + (uint32_t)p * 96u), 0, 0, 0);
+        };
+        // first pass: candidates 0..63, lane = candidate; a lane without a candidate compares candidate 0's chunk
+        // (24-bit multiplies: a full v_mul_lo_u32 issues at a quarter of the rate)
+        const uint32_t cc = lane < u.ncand ? (uint32_t)lane : 0u;
+        const uint32_t ci = __umul24(cc, u.inv_ncj) >> 16, cj = cc - __umul24(ci, (uint32_t)u.ncj);
+        uint32_t roff = __umul24((uint32_t)u.i_min + STEP * ci, wstride4) + ((uint32_t)u.bl * (kBitsWA * 4) + cj * 16u);
+        uint32_t ra[kBitsT], rb[kBitsT];
+        SPlanes pa, pb;
+        prefetch(0);
+        bits_ld_chunk_buf(ra, r_t, roff);
+        prefetch(1);
+        const uint32_t sr = A->sums[(size_t)u.blk * kMe16SumStride + cc];
+        splanes_issue(pa, cblk, 0u);
+        asm volatile("" : "+v"(sd));   // the record's first use (and the wait it draws) stays behind the requests
+        const bool st = lane >= u.nf || (!A->never_static && sd <= A->thresh);
+        const uint32_t skip = (uint32_t)__ballot(st) & ((1u << NF) - 1u);   // bit f: nothing to search for frame f0 + f
 
         uint32_t best[NF];
 #pragma unroll
         for (int f = 0; f < NF; f++) best[f] = 0xFFFFFFFFu;
 
-        const size_t wstride = (size_t)na * kBitsWA;      // dwords per window row of rtab
-        const uint32_t *__restrict__ cblk = cpl + ((size_t)f0 * g.N + blk) * kBitsBlk;
-        const size_t cfs = (size_t)g.N * kBitsBlk;         // dwords per frame of cpl
-
-        if (skip != (1u << NF) - 1u && ncand > 0) {
-            // The planes of the wave's NF current blocks arrive by LDS-direct loads, one instruction
-            // per row pair (lane = (frame, 16-byte piece)), two rounds ahead of their use.  They are
-            // read twice: by the first pass through s_load from L2 -- a scalar load that misses L2
-            // takes ~2,000 cycles and a wave has one in flight; the LDS-direct load is what brings the
-            // line into L2 in time (measured: 0.49 ms without, 0.22 ms with every plane load hitting)
-            // -- and by the second pass from LDS.
-            const __amdgpu_buffer_rsrc_t r_c = buf_rsrc(cblk, 0xFFFFFFFFu);
-            const int pf_f = min(lane / 6, nf - 1), pf_q = lane - (lane / 6) * 6;
-            const uint32_t pf_off = (uint32_t)pf_f * (uint32_t)(cfs * 4) + 16u * (uint32_t)pf_q;
-            auto prefetch = [&](int p) {
-                if (lane < NF * 6)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        r_c, (__attribute__((address_space(3))) void *)(s_c + p * (NF * 96)), 16,
-                        (int)(pf_off + (uint32_t)p * 96u), 0, 0, 0);
+        const bool searching = u.ncand > 0 && skip != (1u << NF) - 1u;
+        // The planes of (frame 0, row pair 0) are collected here, beside the records' round trip: from here
+        // on the compiler may move them (it did, into other registers at the loop's head, while they were
+        // still in flight: tools/check_smem_pipeline.py).
+        splanes_wait(pa);
+        if (!searching)   // nothing may be in flight when the wave ends (the LDS-direct loads write LDS)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (searching) {
+            // ---- first pass: planes of the block in SGPRs ----------------------------------------
+            uint32_t acc[NF];
+#pragma unroll
+            for (int f = 0; f < NF; f++) acc[f] = 0;
+            // One round = one row pair: the chunk of the round is in `cur`; the next round's chunk
+            // and the LDS-direct load two rounds ahead are requested behind the first frame.
+            // Frames go ONE AT A TIME through two plane buffers: while frame f is compared out of
+            // one, frame f + 1 (the next round's frame 0 behind the last) is on its way into the
+            // other -- a scalar load that hits L2 still takes a few hundred cycles, which the 27
+            // vector instructions of a frame (x the other waves of the SIMD) cover.  (Round 3
+            // waited once per PAIR of frames with nothing in flight, and compared a group's
+            // missing eighth frame because the pair was one block of code: 29 frames = 8, 7, 7, 7
+            // cost 32 frame comparisons per candidate, now 29.)
+            // (what the loop needs is derived inside it from three scalars made opaque per round --
+            // otherwise hipcc hoists the 8 frame offsets and the 8 skip tests, as 64-bit lane masks,
+            // out of the loop and spills them around the 48 plane registers)
+            const int last = u.nf - 1;
+            auto round = [&](const uint32_t (&cur)[kBitsT], uint32_t (&nxt)[kBitsT], int p, bool has_next) {
+                uint32_t sk = skip, fs = cfs4, lf = (uint32_t)last;
+                asm volatile("" : "+s"(sk), "+s"(fs), "+s"(lf));
+                const uint32_t po = (uint32_t)p * 96u;
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+                    SPlanes &mine = (f & 1) ? pb : pa;
+                    SPlanes &other = (f & 1) ? pa : pb;
+                    splanes_wait(mine);
+                    // (behind the last round the request repeats row pair 7 of frame 0: harmless, and no
+                    // branch around a statement whose registers are in flight)
+                    splanes_issue(other, cblk, f + 1 < NF ? min((uint32_t)(f + 1), lf) * fs + po : (uint32_t)min(p + 1, 7) * 96u);
+                    if (!((sk >> f) & 1u)) acc[f] = bits_count_lt_s(cur, mine, acc[f]);   // scalar branch
+                    if (f == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (has_next) {
+                            roff += 2u * wstride4;
+                            bits_ld_chunk_buf(nxt, r_t, roff);
+                        }
+                        if (p + 2 < 8) prefetch(p + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             };
-            prefetch(0);
-            prefetch(1);
-
-            // ---- first pass: candidates 0..63, lane = candidate, planes of the block in SGPRs ------
-            {
-                const bool act = lane < ncand;
-                const int cc = act ? lane : 0;
-                const int ci = (int)(((uint32_t)cc * inv_ncj) >> 16), cj = cc - ci * ncj;
-                const uint32_t sr = sums[(size_t)blk * kMe16SumStride + cc];
-                const uint32_t *__restrict__ rp =
-                    rtab + (size_t)(i_min + STEP * ci) * wstride + (size_t)bl * kBitsWA + cj * 4;
-                uint32_t acc[NF];
-#pragma unroll
-                for (int f = 0; f < NF; f++) acc[f] = 0;
-                // one round = one row pair: the chunk of the round is in `cur`; the next round's chunk
-                // and the planes two rounds ahead are requested behind the first frame (the wait that
-                // frame's first use of `cur` draws covers everything issued a round ago, nothing newer)
-                // Frames go in pairs: the planes of both (2 x 24 SGPRs) are requested together and
-                // waited for once -- a scalar load that hits L2 still takes a few hundred cycles and a
-                // wave has nothing else to do meanwhile; per pair the wait is paid once.  A pair is
-                // compared if either frame is searched (the other one's counts are never used).
-                auto round = [&](const uint32_t (&cur)[kBitsT], uint32_t (&nxt)[kBitsT], int p, bool has_next) {
-                    auto planes = [&](uint32_t (&cs)[kBitsT], int f) {
-#ifdef VCS_EXP_BITS_SAMEC   // experiment builds only (results are wrong): every plane load hits the scalar cache
-                        const uint32_t *__restrict__ c = cblk + (f & 1) * kBitsT;
-#else
-                        const uint32_t *__restrict__ c = cblk + (size_t)min(f, nf - 1) * cfs + p * kBitsT;
-#endif
-#pragma unroll
-                        for (int t = 0; t < kBitsT; t++) cs[t] = c[t];
-                    };
-#pragma unroll
-                    for (int f = 0; f < NF; f += 2) {
-                        if (((skip >> f) & 3u) != 3u) {   // scalar branch
-                            uint32_t ca[kBitsT], cb[kBitsT];
-                            planes(ca, f);
-                            if (f + 1 < NF) planes(cb, f + 1);
-                            acc[f] = bits_count_lt(cur, ca, acc[f]);
-                            if (f + 1 < NF) acc[f + 1] = bits_count_lt(cur, cb, acc[f + 1]);
-                        }
-                        if (f == 0) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (has_next) {
-                                rp += 2 * wstride;
-                                bits_ld_chunk(nxt, rp);
-                            }
-                            if (p + 2 < 8) prefetch(p + 2);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                };
-                uint32_t ra[kBitsT], rb[kBitsT];
-                bits_ld_chunk(ra, rp);
 #pragma unroll 1
-                for (int p = 0; p < 8; p += 2) {
-                    round(ra, rb, p, true);
-                    round(rb, ra, p + 1, p + 2 < 8);
-                }
-#pragma unroll
-                for (int f = 0; f < NF; f++)
-                    if (act) best[f] = ((sr + 256u * acc[f]) << 7) | (uint32_t)lane;
+            for (int p = 0; p < 8; p += 2) {
+                round(ra, rb, p, true);
+                round(rb, ra, p + 1, p + 2 < 8);
             }
-
+            splanes_wait(pa);   // the request behind the last round
+            // key = (cost << 7) | candidate, cost = sum(r) - sum(c) + 256 * #{r < c} without the -sum(c),
+            // which is the same for all candidates.  A lane without a candidate has compared candidate
+            // 0's chunk: its key is candidate 0's cost with a higher index, which never wins.
+            const uint32_t base = (sr << 7) | (uint32_t)lane;
+#pragma unroll
+            for (int f = 0; f < NF; f++) best[f] = base + (acc[f] << 15);
+        }
+        // everything is loaded and derived again from here on (see BitsArgs)
+        asm volatile("" : "+s"(ul));
+        const BitsArgsP B = bits_args_again();
+        bits_unit(ul, B, xcd, u);
+        if (searching && u.ncand > 64) {
             // ---- second pass: candidates 64.., lane = (candidate, row pair), planes from LDS ------
-#ifdef VCS_EXP_BITS_NOP2   // experiment builds only (results are wrong): no second pass
-            if (false) {
-#else
-            if (ncand > 64) {
-#endif
-                const int n2 = ncand - 64, ntask = 8 * n2;
-                const uint32_t inv_n2 = 65536u / (uint32_t)n2 + 1u;   // t / n2 for t < 288, n2 <= 36
-                if (lane < 40) {
+            // n2 candidates x 8 row pairs = up to 288 tasks = 4.5 wave passes.  The half-filled last
+            // pass splits the FRAMES between the wave's halves (lanes 32.. repeat the tasks of lanes
+            // 0..31 for frames NF/2..): 4.5 passes cost 4.5, not 5.
+            const int n2 = u.ncand - 64, ntask = 8 * n2;
+            const uint32_t inv_n2 = kBitsInv[n2];   // t / n2 for t < 288, n2 <= 36
+            const uint32_t wstride4b = (uint32_t)B->na * (kBitsWA * 4);
+            const __amdgpu_buffer_rsrc_t r_t2 = buf_rsrc(B->rtab, 0xFFFFFFFFu);
+            if (lane < 40) {
 #pragma unroll
-                    for (int f = 0; f < (NF + 1) / 2; f++) s_part[f * 40 + lane] = 0;
-                }
-                // the LDS-direct loads have landed (this wave's own: its vmcnt is what orders them)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                wave_lds_fence();
-                for (int j = 0; j * 64 < ntask; j++) {
-                    const int t = lane + 64 * j;
-                    const bool act = t < ntask;
-                    const int tc = act ? t : 0;
-                    const int p = (int)(((uint32_t)tc * inv_n2) >> 16), ck = tc - p * n2;
-                    const int cand = 64 + ck;
-                    const int ci = (int)(((uint32_t)cand * inv_ncj) >> 16), cj = cand - ci * ncj;
-                    uint32_t r[kBitsT];
-                    bits_ld_chunk(r, rtab + (size_t)(i_min + STEP * ci + 2 * p) * wstride + (size_t)bl * kBitsWA + cj * 4);
-                    const uint4 *cq = (const uint4 *)(s_c + p * (NF * 96));
+                for (int f = 0; f < (NF + 1) / 2; f++) s_part[f * 40 + lane] = 0;
+            }
+            // the LDS-direct loads have landed (this wave's own: its vmcnt is what orders them)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            // (Requesting pass j + 1's chunk before pass j is compared -- the first pass's two chunk buffers in
+            // turn -- needs 93 registers with the 24 of the planes: five waves per SIMD instead of six, or
+            // scratch traffic in the frame loop when capped at 80.  Not built in.)
+            for (int j = 0; j * 64 < ntask; j++) {
+                const bool split = ntask - 64 * j <= 32;           // the frames go to the two halves of the wave
+                const int half = split ? lane >> 5 : 0;
+                const int t = 64 * j + (split ? lane & 31 : lane);
+                const bool act = t < ntask;
+                const uint32_t tc = act ? (uint32_t)t : 0u;
+                const uint32_t p = __umul24(tc, inv_n2) >> 16, ck = tc - __umul24(p, (uint32_t)n2);
+                const uint32_t cand = 64u + ck;
+                const uint32_t ci2 = __umul24(cand, u.inv_ncj) >> 16, cj2 = cand - __umul24(ci2, (uint32_t)u.ncj);
+                bits_ld_chunk_buf(ra, r_t2, __umul24((uint32_t)u.i_min + STEP * ci2 + 2u * p, wstride4b) +
+                                                ((uint32_t)u.bl * (kBitsWA * 4) + cj2 * 16u));
+                // frame of slot f: f (whole pass) or f + half * NF / 2, slots NF / 2.. unused (split pass)
+                const uint4 *cq = (const uint4 *)(s_c + p * (NF * 96) + half * (NF / 2 * 96));
+                // (a lane without a task adds to slot 39, which no candidate owns: no branch around the add; a
+                // lane whose own frame is static adds to that frame's count, which nobody uses)
+                uint32_t *part = s_part + half * (NF / 4 * 40) + (act ? ck : 39u);
+                const uint32_t sk = split ? ((skip & (skip >> (NF / 2))) | (0xFFu << (NF / 2))) : skip;   // scalar: slot has no frame to do
 #pragma unroll
-                    for (int f = 0; f < NF; f++) {
-                        if (!((skip >> f) & 1u)) {   // scalar branch
-                            uint32_t cs[kBitsT];
+                for (int f = 0; f < NF; f++) {
+                    if (!((sk >> f) & 1u)) {   // scalar branch
+                        uint32_t cs[kBitsT];
 #pragma unroll
-                            for (int q = 0; q < 6; q++) {
-                                const uint4 v = cq[f * 6 + q];
-                                cs[4 * q] = v.x; cs[4 * q + 1] = v.y; cs[4 * q + 2] = v.z; cs[4 * q + 3] = v.w;
-                            }
-                            const uint32_t cnt = bits_count_lt(r, cs, 0u);
-                            if (act) atomicAdd(&s_part[(f >> 1) * 40 + ck], cnt << (16 * (f & 1)));
+                        for (int q = 0; q < 6; q++) {
+                            const uint4 v = cq[f * 6 + q];
+                            cs[4 * q] = v.x; cs[4 * q + 1] = v.y; cs[4 * q + 2] = v.z; cs[4 * q + 3] = v.w;
                         }
+                        const uint32_t cnt = bits_count_lt(ra, cs, 0u);
+                        atomicAdd(&part[(f >> 1) * 40], cnt << (16 * (f & 1)));
                     }
                 }
-                wave_lds_fence();
-                if (lane < n2) {
-                    const uint32_t sr2 = sums[(size_t)blk * kMe16SumStride + 64 + lane];
+            }
+            wave_lds_fence();
+            if (lane < n2) {
+                const uint32_t base2 = (B->sums[(size_t)u.blk * kMe16SumStride + 64 + lane] << 7) | (uint32_t)(64 + lane);
 #pragma unroll
-                    for (int f = 0; f < NF; f++)
-                        best[f] = min(best[f], ((sr2 + 256u * ((s_part[(f >> 1) * 40 + lane] >> (16 * (f & 1))) & 0xFFFFu)) << 7) |
-                                               (uint32_t)(64 + lane));
+                for (int f = 0; f < NF; f++) {
+                    const uint32_t w = s_part[(f >> 1) * 40 + lane];
+                    best[f] = min(best[f], base2 + (((f & 1) ? w >> 16 : w & 0xFFFFu) << 15));
                 }
-                wave_lds_fence();   // the next unit would rewrite s_part (one unit per wave today)
             }
         }
 
         // ---- arg-min per frame (motion.py:149: strict <, raster order = lowest index on ties) -----
-        // the winning key of frame f goes to lane f, which decodes and stores its frame's result
+        // Through LDS (the planes' area is free now): the 64 keys of frame f go to row f, lane
+        // (f, s) takes the minimum of keys 8 s .. 8 s + 7 and three DPP steps finish it inside the
+        // 8 lanes of a frame -- 7 vector instructions for all frames (a wave reduction per frame: 13 each).
+        // Lane 8 f then decodes and stores frame f's result.
         uint32_t my_key = 0xFFFFFFFFu;
+        if (searching) {
+            uint32_t *s_red = (uint32_t *)s_c;
+            wave_lds_fence();   // the second pass's reads of the planes are done
 #pragma unroll
-        for (int f = 0; f < NF; f++) {
-            if (!((skip >> f) & 1u)) {   // scalar
-                const uint32_t key = wave_min_u32(best[f]);
-                if (lane == f) my_key = key;
+            for (int f = 0; f < NF; f++) s_red[f * 64 + lane] = best[f];
+            wave_lds_fence();
+            if (lane < NF * 8) {
+                const uint4 a = *(const uint4 *)(s_red + lane * 8), b = *(const uint4 *)(s_red + lane * 8 + 4);
+                my_key = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
             }
+            my_key = min(my_key, dpp_u32<0xB1>(my_key));    // quad_perm:[1,0,3,2]
+            my_key = min(my_key, dpp_u32<0x4E>(my_key));    // quad_perm:[2,3,0,1]
+            my_key = min(my_key, dpp_u32<0x141>(my_key));   // row_half_mirror: the other quad of the 8 lanes
         }
-        if (lane < nf) {
-            const size_t o = (size_t)(f0 + lane) * g.N + blk;
-            const uint2 bi = binfo[o];
+        const int fr = lane >> 3;
+        if ((lane & 7) == 0 && fr < u.nf) {
+            const size_t o = (size_t)(u.f0 + fr) * B->N + u.blk;
+            const uint2 bi = B->binfo[o];
             uint32_t mvw = 0u;
             unsigned long long cw = bi.x;              // static block: [0, 0], cost = the difference
-            if (!((skip >> lane) & 1u)) {
+            if (!((skip >> fr) & 1u)) {
                 int bx = 0, byy = 0;
                 cw = 9999999999ull;                    // motion.py:120: no candidate
                 if (my_key != 0xFFFFFFFFu) {
                     const int cb = (int)(my_key & 127u);
-                    const int cbi = (int)(((uint32_t)cb * inv_ncj) >> 16);
-                    byy = i_min + cbi * STEP;
-                    bx = j_min + (cb - cbi * ncj) * STEP;
+                    const int cbi = (int)(((uint32_t)cb * u.inv_ncj) >> 16);
+                    byy = u.i_min + cbi * STEP;
+                    bx = u.j_min + (cb - cbi * u.ncj) * STEP;
                     cw = (my_key >> 7) - bi.y;
                 }
-                mvw = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);  // [dx, dy]
+                mvw = (uint32_t)(uint16_t)(bx - u.x) | ((uint32_t)(uint16_t)(byy - u.y) << 16);  // [dx, dy]
             }
-            *(uint32_t *)(mv + 2 * o) = mvw;
-            if (cost_out) cost_out[o] = cw;
+            *(uint32_t *)(B->mv + 2 * o) = mvw;
+            if (B->cost_out) B->cost_out[o] = cw;
         }
     }
     // (one workgroup in 64 reports: 8,040 workgroups adding to the same two words serialise in L2 --
     // ~12 ns per atomic -- and a wave keeps its slot until its atomics are done: with every workgroup
     // reporting, the instrumented launch could not end before 8,040 x 25 ns = 0.2 ms)
-    if (clk_out && threadIdx.x == 0 && (blockIdx.x & 63u) == 0) {
+    if (clocked) {
+        unsigned long long *clk_out = bits_args_again()->clk_out;
         atomicAdd(clk_out + 12, __builtin_amdgcn_s_memtime() - clk0);
         atomicAdd(clk_out + 13, __builtin_amdgcn_s_memrealtime() - rt0);
     }
@@ -724,10 +838,14 @@ inline void launch_bits_search(const Geom &g, hipStream_t stream, const uint32_t
     int pf8 = pf_base ? (npf_env > 0 ? npf_env : 384 * 4 / kBitsWpw) / 8 : 0;   // 1,536 prefetch waves
     if (pf8 * ratio > nsearch / 8) pf8 = nsearch / 8 / ratio;
     if (pf8 == 0) pf_base = nullptr;
-    hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(nsearch + 8 * pf8), dim3(64 * kBitsWpw), 0, stream, ev_start, ev_stop, 0,
-                          rtab, cpl, binfo, sums, g, n, ngroups, mv, cost, clk, pf_base,
-                          (uint32_t)(pf_base ? pf_bytes >> 4 : 0), nsearch, pf8, ratio, ns_part, me_bits_cur_wgs(g), ns,
-                          a0, na, magic_u32((uint32_t)(g.nby * ngroups)), magic_u32((uint32_t)ngroups));
+    BitsArgs a;
+    a.rtab = rtab; a.cpl = cpl; a.binfo = binfo; a.sums = sums; a.mv = mv; a.cost_out = cost; a.clk_out = clk;
+    a.pf_base = pf_base; a.ns_part = ns_part; a.n_static = ns;
+    a.H = g.H; a.W = g.W; a.N = g.N; a.nbx = g.nbx; a.nby = g.nby; a.thresh = g.thresh; a.never_static = g.never_static;
+    a.n_frames = n; a.ngroups = ngroups; a.pf_total16 = (uint32_t)(pf_base ? pf_bytes >> 4 : 0);
+    a.n_search_wgs = nsearch; a.pf_octets = pf8; a.pf_ratio = ratio; a.ns_per_frame = me_bits_cur_wgs(g);
+    a.a0 = a0; a.na = na; a.per_col_magic = magic_u32((uint32_t)(g.nby * ngroups)); a.ngroups_magic = magic_u32((uint32_t)ngroups);
+    hipExtLaunchKernelGGL((k_me16b<kBitsNF>), dim3(nsearch + 8 * pf8), dim3(64 * kBitsWpw), 0, stream, ev_start, ev_stop, 0, a);
 }
 
 }  // namespace vcs
