@@ -435,6 +435,9 @@ def main():
     n_gpus = world if world > 1 else n_local
     use_group = args.group or n_gpus > 1
     args.with_decode = args.with_decode or not args.no_extras   # second line of SURVEY 8d
+    # VCS_BENCH_REF_PIPELINE=0: every step declares its I frame only when it starts (round 3's loop): the
+    # per-reference tables are then cut in front of each GOP's search instead of beside the previous one's
+    pipelined_ref = os.environ.get("VCS_BENCH_REF_PIPELINE", "1") != "0" and not args.same_ref
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a
     # version banner), so file descriptor 1 is pointed at stderr for the whole run and the
     # line goes to a private copy of the original stdout.
@@ -532,6 +535,8 @@ def main():
         group.set_ref(ref)               # the I frame enters HBM on GPU 0 only (no-op elsewhere)
     else:
         ctx.set_ref(ref)
+        if pipelined_ref:
+            ctx.set_ref_next(ref)
     state = {"k": 0}
 
     def step(rot=sets):
@@ -545,7 +550,14 @@ def main():
         # every step is a new GOP: the per-reference work (the sum table) is redone inside
         # the timed region, once per GOP as in a real encode
         if not args.same_ref:
-            ctx.ref_written()
+            if pipelined_ref:
+                # the double-buffered reference of a stream of GOPs: this GOP's I frame was staged in the
+                # alternate buffer while the previous GOP was encoded (here: the same picture, staged once),
+                # and the library cut its search tables beside the previous GOP's search kernel
+                ctx.ref_swap()
+                ctx.ref_next_ready()
+            else:
+                ctx.ref_written()
         ctx.gop_encode(k * n_total, n_total)   # ME kernel + fused tail kernel
 
     def fence():

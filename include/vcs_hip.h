@@ -296,6 +296,20 @@ int vcs_ref_written(vcs_ctx *ctx);
  * the buffer it was launched with.  After a swap, vcs_dev_ptr(0 / 3) return
  * the exchanged pointers.                                                    */
 int vcs_ref_swap(vcs_ctx *ctx);
+/* Declares the ALTERNATE reference buffer complete: it holds the next GOP's I
+ * frame (encoder.py:41-43: the frame a later vcs_ref_swap makes current), as
+ * of the work enqueued so far on `written_on_stream` (a hipStream_t; null =
+ * the context's own stream order, e.g. after a copy the caller enqueued behind
+ * vcs_stream_wait).  From then on the per-reference tables of the bit-plane
+ * search (what k_bits_ref makes) are cut on a side stream BESIDE the search
+ * kernel of the GOP encoded next, instead of in front of the following GOP's
+ * search; the swap finds them ready.  Purely a scheduling hint: results are the
+ * same with or without it.                                                   */
+int vcs_ref_next_ready(vcs_ctx *ctx, void *written_on_stream);
+/* vcs_set_ref into the alternate buffer + vcs_ref_next_ready: the host-side
+ * form for a caller that knows its next I frame early (main.py:34-43 reads
+ * frames in order: frame n + gop_length is known while GOP n is encoded).     */
+int vcs_set_ref_next(vcs_ctx *ctx, const uint8_t *ref_bgr);
 
 /* ---- intra prediction (next row N1; BASELINE config 5) ------------------ */
 /* IntraframeCompression/intraframe.py: luma4x4 (:24-151), luma16x16 (:153-225)

@@ -197,6 +197,48 @@ def test_ref_swap_alternates_two_resident_references(vh, oracle):
             assert np.array_equal(c.me(cur)[0], want)
 
 
+@pytest.mark.parametrize("bs", [16, 8])
+def test_next_reference_tables_cut_beside_the_search(vh, oracle, bs):
+    """vcs_set_ref_next / vcs_ref_next_ready: the next GOP's I frame is staged in the alternate buffer and the
+    bit-plane search's per-reference tables are cut on a side stream beside this GOP's search kernel.  Three
+    GOPs with three DIFFERENT I frames, each staged while the previous GOP is encoded; a fourth whose I
+    frame arrives late (plain set_ref after a swap: the shadow table of the stale content must not be used)."""
+    from synth import synth_gop
+    H, W, n = 144, 176, 7
+    refs, gops = [], []
+    for k in range(4):
+        r, fr = synth_gop(H, W, n, seed=40 + k)
+        refs.append(r)
+        gops.append(fr)
+    with vh.Context(H, W, bs) as c:
+        c.gop_reserve(n)
+        c.set_ref(refs[0])
+        for k in range(3):
+            if k + 1 < 3:
+                c.set_ref_next(refs[k + 1])          # known early: its tables are cut beside GOP k's search
+            c.gop_upload(0, gops[k])
+            c.gop_encode(0, n)
+            mv, ns = c.gop_get_mv(0, n)
+            for f in range(n):
+                want, wns = oracle.me(gops[k][f], refs[k], bs)
+                assert np.array_equal(mv[f], want) and ns[f] == wns, "GOP %d frame %d" % (k, f)
+            assert np.array_equal(c.gop_get_planes(n - 1), oracle.encode_p(gops[k][n - 1], refs[k], bs)[1])
+            if k + 1 < 3:
+                c.ref_swap()
+        # declared ready, then overwritten after the swap: the table cut from the old content is stale
+        c.set_ref_next(refs[0])
+        c.gop_upload(0, gops[2])
+        c.gop_encode(0, n)                           # (cuts refs[0]'s table in the shadow)
+        c.ref_swap()
+        c.set_ref(refs[3])                           # ... but the GOP's I frame turns out to be another one
+        c.gop_upload(0, gops[3])
+        c.gop_encode(0, n)
+        mv, ns = c.gop_get_mv(0, n)
+        for f in range(n):
+            want, wns = oracle.me(gops[3][f], refs[3], bs)
+            assert np.array_equal(mv[f], want) and ns[f] == wns, "late I frame, frame %d" % f
+
+
 def test_pinned_host_buffers(vh, oracle):
     """vcs_host_alloc (frame feeder): frames produced into page-locked memory go
     through the same entry points with the same results; the memory is released with the array."""

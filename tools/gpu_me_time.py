@@ -30,19 +30,33 @@ ref, frames = synth_gop(H, W, n, seed=1234, first=1)
 frames = np.ascontiguousarray(frames)
 if a.static > 0:
     frames[:, :, : int(W * a.static)] = ref[:, : int(W * a.static)]
+# VCS_BENCH_REF_PIPELINE=0: the I frame is declared when its GOP starts (tables cut in front of the search)
+pipe = os.environ.get("VCS_BENCH_REF_PIPELINE", "1") != "0"
+
+
+def new_gop(c):
+    if pipe:
+        c.ref_swap()
+        c.ref_next_ready()
+    else:
+        c.ref_written()
+
+
 with vcs_hip.Context(H, W, a.bs, 8) as c:
     c.set_ref(ref)
+    if pipe:
+        c.set_ref_next(ref)
     c.gop_reserve(a.sets * n)
     for s in range(a.sets):
         c.gop_upload(s * n, frames)
     for k in range(max(3, a.sets)):
-        c.ref_written()
+        new_gop(c)
         c.gop_encode((k % a.sets) * n, n)
     c.sync()
     t_end = time.perf_counter() + 0.25   # clock conditioning, as bench.py
     k = 0
     while time.perf_counter() < t_end:
-        c.ref_written()
+        new_gop(c)
         c.gop_encode((k % a.sets) * n, n)
         k += 1
         if k % 16 == 0:
@@ -52,7 +66,7 @@ with vcs_hip.Context(H, W, a.bs, 8) as c:
     c.timing_reset()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        c.ref_written()
+        new_gop(c)
         c.gop_encode((k % a.sets) * n, n)
     c.sync()
     dt = (time.perf_counter() - t0) / a.steps

@@ -90,29 +90,37 @@ __global__ __launch_bounds__(256) void k_bits_ref(const uint8_t *__restrict__ re
     const uint32_t a = (uint32_t)a0 + wa % (uint32_t)na, w = wa / (uint32_t)na;
     const int j = max(16 * (int)a - 32, 0) + 5 * (int)m;
     const __amdgpu_buffer_rsrc_t r_ref = buf_rsrc(ref, ref_bytes);   // reads past the slack rows return 0
-    const uint32_t off = w * (uint32_t)g.pitch + 3u * (uint32_t)j;
-    uint32_t s[24];
-#pragma unroll
-    for (int i = 0; i < 12; i++) {   // unaligned dwords (tools/buf_test.hip)
-        s[i] = buf_ld32(r_ref, off + 4u * i, 0);
-        s[12 + i] = buf_ld32(r_ref, off + (uint32_t)g.pitch + 4u * i, 0);
-    }
-    if (r2) {
-        uint32_t rs = 0;
-#pragma unroll
-        for (int i = 0; i < 24; i++) rs = __builtin_amdgcn_sad_u8(s[i], 0u, rs);
-        r2[idx] = rs;
-    }
+    uint32_t off = w * (uint32_t)g.pitch + 3u * (uint32_t)j;
+    asm volatile("" : "+v"(off));   // (one register + immediate offsets; seen through, hipcc forms 24 addresses)
+    const uint32_t off2 = off + (uint32_t)g.pitch;
+    // One third of the chunk at a time (8 dwords in, 8 plane dwords out): at most 32 registers, so that a
+    // wave of this kernel fits into what six k_me16b waves leave of a SIMD's register file -- the next GOP's
+    // table is cut beside the search kernel (vcs_ref_next_ready), not in front of the next GOP.
     uint4 *dst = (uint4 *)(rtab + (size_t)wa * kBitsWA + m * 4);
+    uint32_t rs = 0;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         uint32_t x[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = s[8 * d + i];
+        for (int i = 0; i < 8; i++) {   // unaligned dwords (tools/buf_test.hip); string = row w's 12 dwords, then row w + 1's
+            const int t = 8 * d + i;
+            x[i] = t >= 12 ? buf_ld32(r_ref, off2 + 4u * (t - 12), 0) : buf_ld32(r_ref, off + 4u * t, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) rs = __builtin_amdgcn_sad_u8(x[i], 0u, rs);
+        asm volatile("" : "+v"(rs));   // (summed here, not at the end with all 24 dwords kept for it)
         bits_transpose8(x);
+#ifdef VCS_EXP_REF_NT   // experiment build (same results): non-temporal table stores
+        { u32x4_t v0 = {x[0], x[1], x[2], x[3]}, v1 = {x[4], x[5], x[6], x[7]};
+          __builtin_nontemporal_store(v0, (u32x4_t *)&dst[(2 * d) * kBitsM]);
+          __builtin_nontemporal_store(v1, (u32x4_t *)&dst[(2 * d + 1) * kBitsM]); }
+#else
         dst[(2 * d) * kBitsM] = make_uint4(x[0], x[1], x[2], x[3]);
         dst[(2 * d + 1) * kBitsM] = make_uint4(x[4], x[5], x[6], x[7]);
+#endif
+        __builtin_amdgcn_sched_barrier(0);   // (the next third's loads stay behind this third's stores)
     }
+    if (r2) r2[idx] = rs;
 }
 
 // ---- current blocks -----------------------------------------------------------------------
@@ -443,6 +451,27 @@ __device__ __forceinline__ bool bits_unit(int ul, BitsArgsP A, int xcd, BitsUnit
     return true;
 }
 
+// The second pass's task of a lane in wave pass j (candidates 64.., lane = (candidate, row pair); the
+// half-filled last pass gives the two halves of the wave the same tasks for different frames).
+struct BitsTask { uint32_t p, ck, off; int half; bool act; };
+__device__ __forceinline__ BitsTask bits_task(int j, int lane, int n2, uint32_t inv_n2, const BitsUnit &u, uint32_t wstride4) {
+    constexpr int STEP = 5;
+    const int ntask = 8 * n2;
+    const bool split = ntask - 64 * j <= 32;
+    BitsTask k;
+    k.half = split ? lane >> 5 : 0;
+    const int t = 64 * j + (split ? lane & 31 : lane);
+    k.act = t < ntask;
+    const uint32_t tc = k.act ? (uint32_t)t : 0u;
+    // (24-bit multiplies: a full v_mul_lo_u32 issues at a quarter of the rate)
+    k.p = __umul24(tc, inv_n2) >> 16;
+    k.ck = tc - __umul24(k.p, (uint32_t)n2);
+    const uint32_t cand = 64u + k.ck;
+    const uint32_t ci = __umul24(cand, u.inv_ncj) >> 16, cj = cand - __umul24(ci, (uint32_t)u.ncj);
+    k.off = __umul24((uint32_t)u.i_min + STEP * ci + 2u * k.p, wstride4) + ((uint32_t)u.bl * (kBitsWA * 4) + cj * 16u);
+    return k;
+}
+
 template <int NF>
 __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value) {
     constexpr int STEP = 5;
@@ -605,6 +634,9 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
                         if (has_next) {
                             roff += 2u * wstride4;
                             bits_ld_chunk_buf(nxt, r_t, roff);
+                        } else if (u.ncand > 64) {   // the second pass's first chunk, into the buffer the last round leaves free
+                            const int n2 = u.ncand - 64;
+                            bits_ld_chunk_buf(nxt, r_t, bits_task(0, lane, n2, kBitsInv[n2], u, wstride4).off);
                         }
                         if (p + 2 < 8) prefetch(p + 2);
                         __builtin_amdgcn_sched_barrier(0);
@@ -644,20 +676,16 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
             // the LDS-direct loads have landed (this wave's own: its vmcnt is what orders them)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_lds_fence();
-            // (Requesting pass j + 1's chunk before pass j is compared -- the first pass's two chunk buffers in
-            // turn -- needs 93 registers with the 24 of the planes: five waves per SIMD instead of six, or
-            // scratch traffic in the frame loop when capped at 80.  Not built in.)
+            // (Requesting EVERY pass's chunk a pass ahead -- the first pass's two chunk buffers in turn -- needs
+            // 93 registers with the 24 of the planes: five waves per SIMD instead of six, or scratch traffic
+            // in the frame loop when capped at 80.  Only pass 0's is ahead.)
             for (int j = 0; j * 64 < ntask; j++) {
                 const bool split = ntask - 64 * j <= 32;           // the frames go to the two halves of the wave
-                const int half = split ? lane >> 5 : 0;
-                const int t = 64 * j + (split ? lane & 31 : lane);
-                const bool act = t < ntask;
-                const uint32_t tc = act ? (uint32_t)t : 0u;
-                const uint32_t p = __umul24(tc, inv_n2) >> 16, ck = tc - __umul24(p, (uint32_t)n2);
-                const uint32_t cand = 64u + ck;
-                const uint32_t ci2 = __umul24(cand, u.inv_ncj) >> 16, cj2 = cand - __umul24(ci2, (uint32_t)u.ncj);
-                bits_ld_chunk_buf(ra, r_t2, __umul24((uint32_t)u.i_min + STEP * ci2 + 2u * p, wstride4b) +
-                                                ((uint32_t)u.bl * (kBitsWA * 4) + cj2 * 16u));
+                const BitsTask tk = bits_task(j, lane, n2, inv_n2, u, wstride4b);
+                const int half = tk.half;
+                const uint32_t p = tk.p, ck = tk.ck;
+                const bool act = tk.act;
+                if (j > 0) bits_ld_chunk_buf(ra, r_t2, tk.off);   // (pass 0's chunk was requested in the first pass's last round)
                 // frame of slot f: f (whole pass) or f + half * NF / 2, slots NF / 2.. unused (split pass)
                 const uint4 *cq = (const uint4 *)(s_c + p * (NF * 96) + half * (NF / 2 * 96));
                 // (a lane without a task adds to slot 39, which no candidate owns: no branch around the add; a
@@ -712,23 +740,26 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
         const int fr = lane >> 3;
         if ((lane & 7) == 0 && fr < u.nf) {
             const size_t o = (size_t)(u.f0 + fr) * B->N + u.blk;
-            const uint2 bi = B->binfo[o];
-            uint32_t mvw = 0u;
-            unsigned long long cw = bi.x;              // static block: [0, 0], cost = the difference
-            if (!((skip >> fr) & 1u)) {
-                int bx = 0, byy = 0;
-                cw = 9999999999ull;                    // motion.py:120: no candidate
-                if (my_key != 0xFFFFFFFFu) {
+            const bool searched = !((skip >> fr) & 1u), found = searched && my_key != 0xFFFFFFFFu;
+            uint32_t mvw = 0u;                         // static block: [0, 0]
+            if (searched) {
+                int bx = 0, byy = 0;                   // motion.py:120: no candidate
+                if (found) {
                     const int cb = (int)(my_key & 127u);
                     const int cbi = (int)(((uint32_t)cb * u.inv_ncj) >> 16);
                     byy = u.i_min + cbi * STEP;
                     bx = u.j_min + (cb - cbi * u.ncj) * STEP;
-                    cw = (my_key >> 7) - bi.y;
                 }
                 mvw = (uint32_t)(uint16_t)(bx - u.x) | ((uint32_t)(uint16_t)(byy - u.y) << 16);  // [dx, dy]
             }
             *(uint32_t *)(B->mv + 2 * o) = mvw;
-            if (B->cost_out) B->cost_out[o] = cw;
+            // costs are a debugging output: only then is the block's record read again (a round trip at the end
+            // of every wave otherwise)
+            if (B->cost_out) {
+                const uint2 bi = B->binfo[o];
+                B->cost_out[o] = !searched ? (unsigned long long)bi.x      // static: the difference
+                                 : found ? (unsigned long long)((my_key >> 7) - bi.y) : 9999999999ull;
+            }
         }
     }
     // (one workgroup in 64 reports: 8,040 workgroups adding to the same two words serialise in L2 --

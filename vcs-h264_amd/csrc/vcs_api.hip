@@ -67,10 +67,28 @@ struct vcs_ctx {
     bool sums_valid = false;
     // k_me16b (me_bits.hpp): the reference cut into bit-plane chunks (per reference frame), the
     // current blocks as bit planes + {static-test sum, sum(c)} per block (scratch, per launch)
-    uint32_t *d_rtab = nullptr, *d_cpl = nullptr;
+    uint32_t *d_rtab = nullptr, *d_cpl = nullptr;   // d_rtab: the chunk table in use (one of tabs[].tab)
     uint2 *d_binfo = nullptr;
     int cpl_frames = 0;      // frames d_cpl / d_binfo hold
     bool rtab_valid = false;
+    bool bits_unusable = false;   // the scratch could not be allocated: the shared-window kernels serve this context
+    // Two chunk tables, each tied to the reference buffer it was cut from.  The second exists for the
+    // SHADOW BUILD: once the caller has declared the alternate reference buffer complete
+    // (vcs_ref_next_ready), the next GOP's table is cut on a side stream beside this GOP's search kernel
+    // (vector-issue bound, ~15 % of its issue slots idle and a drain phase at its end) instead of as a
+    // serial 28 us kernel in front of the next GOP; vcs_ref_swap / the group's buffer exchange then finds
+    // it `fresh`.
+    struct RefTable {
+        uint32_t *tab = nullptr;
+        const uint8_t *for_ref = nullptr;   // reference buffer the table was cut from
+        bool fresh = false;                 // cut from content the search has not used yet (shadow build)
+        bool pending = false;               // ev_done has to be waited for before the table is read
+        hipEvent_t ev_done = nullptr;
+    } tabs[2];
+    bool next_ready = false;        // the alternate reference buffer holds the next GOP's I frame
+    hipEvent_t ev_next = nullptr;   // ... as of this event (recorded on the stream that wrote it)
+    hipStream_t s_side = nullptr;
+    hipEvent_t ev_side_go = nullptr;
     int cus = 256;         // compute units of the device
     // single-frame buffers
     uint8_t *d_ref = nullptr, *d_cur = nullptr, *d_a = nullptr, *d_b = nullptr;
@@ -251,9 +269,21 @@ int launch_me_generic_t(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, siz
 
 // Scratch of the bit-plane search for n frames (grown on demand; allocation synchronises, so it
 // happens on the first launch of a given size only).
+static size_t bits_table_bytes(const vcs_ctx *c) {
+    return c->g.bs == 8 ? me_bits8_rtab_bytes(c->g) : me_bits_rtab_bytes(c->g);   // (a context has one block size: the 8x8 and 16x16 forms never mix)
+}
+// On an allocation failure the bit-plane path is marked unusable for this context and the caller falls
+// through to the shared-window kernels, which need no scratch (VCS_TEST_BITS_NOMEM=1 forces that path).
 static int ensure_bits(vcs_ctx *c, int n) {
-    const bool b8 = c->g.bs == 8;   // (a context has one block size: the 8x8 and 16x16 forms never mix)
-    if (!c->d_rtab) HIP_TRY(c, hipMalloc(&c->d_rtab, b8 ? me_bits8_rtab_bytes(c->g) : me_bits_rtab_bytes(c->g)));
+    static const bool test_nomem = [] { const char *e = getenv("VCS_TEST_BITS_NOMEM"); return e && e[0] == '1'; }();
+    const bool b8 = c->g.bs == 8;
+    auto give_up = [&] {
+        (void)hipGetLastError();
+        c->bits_unusable = true;
+        return VCS_E_HIP;
+    };
+    if (test_nomem) return give_up();
+    if (!c->tabs[0].tab && hipMalloc(&c->tabs[0].tab, bits_table_bytes(c)) != hipSuccess) return give_up();
     if (n > c->cpl_frames) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         hipFree(c->d_cpl);
@@ -261,10 +291,83 @@ static int ensure_bits(vcs_ctx *c, int n) {
         c->d_cpl = nullptr;
         c->d_binfo = nullptr;
         c->cpl_frames = 0;
-        HIP_TRY(c, hipMalloc(&c->d_cpl, b8 ? me_bits8_cpl_bytes(c->g, n) : me_bits_cpl_bytes(c->g, n)));
-        HIP_TRY(c, hipMalloc(&c->d_binfo, b8 ? me_bits8_binfo_bytes(c->g, n) : me_bits_binfo_bytes(c->g, n)));
+        if (hipMalloc(&c->d_cpl, b8 ? me_bits8_cpl_bytes(c->g, n) : me_bits_cpl_bytes(c->g, n)) != hipSuccess ||
+            hipMalloc(&c->d_binfo, b8 ? me_bits8_binfo_bytes(c->g, n) : me_bits_binfo_bytes(c->g, n)) != hipSuccess) {
+            hipFree(c->d_cpl);
+            c->d_cpl = nullptr;
+            return give_up();
+        }
         c->cpl_frames = n;
     }
+    return VCS_OK;
+}
+
+static void bits_cut_table(vcs_ctx *c, hipStream_t st, const uint8_t *ref, uint32_t *tab) {
+    if (c->g.bs == 8)
+        launch_bits_ref8(c->g, st, ref, c->Fs + me_fast_ref_slack(c->g), tab, tab + me_bits8_table_words(c->g));
+    else
+        launch_bits_ref(c->g, st, ref, c->Fs + me_fast_ref_slack(c->g), tab, 0, c->g.nbx, tab + me_bits_table_words(c->g));
+}
+
+// The chunk table of `ref` (one band), whose content is new since the table in use was cut: the one cut in
+// the shadow of the previous GOP's search if there is one, else cut now, in front of the search.
+static int bits_table_for(vcs_ctx *c, const uint8_t *ref) {
+    int i = c->tabs[0].for_ref == ref && c->tabs[0].fresh ? 0 : c->tabs[1].for_ref == ref && c->tabs[1].fresh ? 1 : -1;
+    if (i < 0) {   // cut it now; into the table that is not waiting for its turn
+        i = c->tabs[0].fresh ? 1 : 0;
+        vcs_ctx::RefTable &t = c->tabs[i];
+        if (!t.tab) HIP_TRY(c, hipMalloc(&t.tab, bits_table_bytes(c)));
+        if (t.pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, t.ev_done, 0));
+        t.pending = false;
+        bits_cut_table(c, c->stream, ref, t.tab);
+        HIP_TRY(c, hipGetLastError());
+        t.for_ref = ref;
+    }
+    vcs_ctx::RefTable &t = c->tabs[i];
+    if (t.pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, t.ev_done, 0));
+    t.pending = false;
+    t.fresh = false;
+    c->d_rtab = t.tab;
+    c->rtab_valid = true;
+    return VCS_OK;
+}
+
+// The shadow build: the next GOP's table, from the alternate reference buffer, on a side stream that
+// starts where the main stream is now (right in front of the search kernel).  Failures (no memory for the
+// second table) just leave the table to be cut in front of the next search.
+static void bits_shadow_build(vcs_ctx *c) {
+    static const bool off = [] { const char *e = getenv("VCS_BITS_SHADOW"); return e && e[0] == '0'; }();
+    if (off || !c->next_ready || !c->d_ref_alt) return;
+    c->next_ready = false;
+    const int j = c->d_rtab == c->tabs[0].tab ? 1 : 0;
+    vcs_ctx::RefTable &t = c->tabs[j];
+    if (!t.tab && hipMalloc(&t.tab, bits_table_bytes(c)) != hipSuccess) { (void)hipGetLastError(); t.tab = nullptr; return; }
+    if (!c->s_side) {
+        if (hipStreamCreateWithFlags(&c->s_side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_side_go, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+    }
+    if (!t.ev_done && hipEventCreateWithFlags(&t.ev_done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+    hipEventRecord(c->ev_side_go, c->stream);
+    hipStreamWaitEvent(c->s_side, c->ev_side_go, 0);
+    if (c->ev_next) hipStreamWaitEvent(c->s_side, c->ev_next, 0);   // the I frame's own arrival (a collective's stream)
+    bits_cut_table(c, c->s_side, c->d_ref_alt, t.tab);
+    hipEventRecord(t.ev_done, c->s_side);
+    (void)hipGetLastError();
+    t.for_ref = c->d_ref_alt;
+    t.fresh = true;
+    t.pending = true;
+}
+
+// The content of reference buffer `buf` is about to change / has changed outside the swap protocol: a
+// table cut from it in the shadow of a search is stale (and, if still being cut, is waited for first).
+static int bits_tables_stale(vcs_ctx *c, const uint8_t *buf) {
+    for (auto &t : c->tabs)
+        if (t.for_ref == buf) {
+            if (t.pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, t.ev_done, 0));
+            t.pending = false;
+            t.fresh = false;
+            t.for_ref = nullptr;
+        }
     return VCS_OK;
 }
 
@@ -272,9 +375,13 @@ static int ensure_bits(vcs_ctx *c, int n) {
 int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride, int n,
               int16_t *mv, uint32_t *ns, unsigned long long *cost, bool force_generic = false) {
     if (c->g.N == 0 || n == 0) return VCS_OK;
-    const bool bits = c->me_fast_ok && !force_generic && me_bits_worthwhile(c->g, n);
+    bool bits = c->me_fast_ok && !force_generic && !c->bits_unusable && me_bits_worthwhile(c->g, n);
     // the per-frame static-block counters start at zero; the rolling kernel's primer does it
-    const bool bits8 = c->me_fast8_ok && !force_generic && me_bits8_worthwhile(c->g, n);
+    bool bits8 = c->me_fast8_ok && !force_generic && !c->bits_unusable && me_bits8_worthwhile(c->g, n);
+    if ((bits || bits8) && ensure_bits(c, n) != VCS_OK) {
+        if (!c->bits_unusable) return VCS_E_HIP;   // (a failure other than the allocation: c->err has it)
+        bits = bits8 = false;
+    }
     const bool roll = !bits && c->me_fast_ok && !force_generic && me16r_worthwhile(c->g, c->cus, n);
     if (!roll && !bits && !bits8) HIP_TRY(c, hipMemsetAsync(ns, 0, sizeof(uint32_t) * n, c->stream));
     // per-reference sum(r) table, once per reference frame (all P frames of a GOP share it);
@@ -291,15 +398,17 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         c->rtab_valid = false;
     }
     if (bits) {
-        int rc = ensure_bits(c, n);
-        if (rc) return rc;
+        int rc;
         const int nb = me_bits_bands(c->g), bc = me_bits_band_cols(c->g);
-        uint32_t *r2 = c->d_rtab + me_bits_table_words(c->g);   // row-pair sums behind the chunk table
-        if (nb == 1 && !c->rtab_valid) {   // one band: the table of a new reference first (k_bits_cur adds its sums up)
-            launch_bits_ref(c->g, c->stream, ref, c->Fs + me_fast_ref_slack(c->g), c->d_rtab, 0, c->g.nbx, r2);
-            HIP_TRY(c, hipGetLastError());
-            c->rtab_valid = true;
+        // one band: the table of a new reference first (k_bits_cur adds its sums up); several: per launch, below
+        if (nb == 1) {
+            if ((!c->rtab_valid || c->tabs[c->d_rtab == c->tabs[1].tab ? 1 : 0].for_ref != ref) &&
+                (rc = bits_table_for(c, ref)))
+                return rc;
+        } else {
+            c->d_rtab = c->tabs[0].tab;
         }
+        uint32_t *r2 = c->d_rtab + me_bits_table_words(c->g);   // row-pair sums behind the chunk table
         EvPair evp;
         if ((rc = t_begin(c, VCS_T_ME_PREP, &evp, /*attach=*/true))) return rc;
         uint32_t *ns_part = (uint32_t *)(c->d_binfo + (size_t)n * c->g.N);   // behind the n * N block records
@@ -321,6 +430,7 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         // it at 4K): with one band it is built once per reference frame, like the sum table; with
         // several it is rebuilt band by band in every launch (25 us per band).
         const bool nc = c->t_no_count;
+        if (nb == 1) bits_shadow_build(c);   // the next GOP's table, beside this search
         for (int band = 0; band < nb && !rc; band++) {
             const int a0 = band * bc, na = std::min(bc, c->g.nbx - a0);
             if (nb > 1) {
@@ -340,14 +450,11 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         return rc;
     }
     if (bits8) {   // the 8x8 bit-plane search (me_bits8.hpp): chunk table per reference, planes, search
-        int rc = ensure_bits(c, n);
-        if (rc) return rc;
+        int rc;
+        if ((!c->rtab_valid || c->tabs[c->d_rtab == c->tabs[1].tab ? 1 : 0].for_ref != ref) &&
+            (rc = bits_table_for(c, ref)))
+            return rc;
         uint32_t *r2 = c->d_rtab + me_bits8_table_words(c->g);   // chunk sums behind the chunk table
-        if (!c->rtab_valid) {
-            launch_bits_ref8(c->g, c->stream, ref, c->Fs + me_fast_ref_slack(c->g), c->d_rtab, r2);
-            HIP_TRY(c, hipGetLastError());
-            c->rtab_valid = true;
-        }
         uint32_t *ns_part = (uint32_t *)(c->d_binfo + (size_t)n * c->g.N);
         EvPair evp, ev;
         if ((rc = t_begin(c, VCS_T_ME_PREP, &evp, /*attach=*/true))) return rc;
@@ -358,6 +465,7 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         static const bool pf_tail_wgs = [] { const char *e = getenv("VCS_BITS_PF"); return !(e && e[0] == '0'); }();
         const bool pf = c->pf_in_search && pf_tail_wgs && (size_t)n * stride < 0xFFFFFFFFull;
         c->pf_in_search = pf;
+        bits_shadow_build(c);   // the next GOP's table, beside this search
         if ((rc = t_begin(c, VCS_T_ME, &ev, /*attach=*/true))) return rc;
         launch_bits_search8(c->g, c->stream, c->d_rtab, c->d_cpl, c->d_binfo, c->d_sums, n, mv, ns_part, ns, cost,
                             pf ? curs : nullptr, (size_t)n * stride, ev.a, ev.b);
@@ -840,7 +948,11 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     hipFree(c->d_coords); hipFree(c->d_cost); hipFree(c->d_ns); hipFree(c->d_planes);
     hipFree(c->d_DQ);
     hipFree(c->d_sums);
-    hipFree(c->d_rtab); hipFree(c->d_cpl); hipFree(c->d_binfo);
+    for (auto &t : c->tabs) { hipFree(t.tab); if (t.ev_done) hipEventDestroy(t.ev_done); }
+    hipFree(c->d_cpl); hipFree(c->d_binfo);
+    if (c->ev_side_go) hipEventDestroy(c->ev_side_go);
+    if (c->ev_next) hipEventDestroy(c->ev_next);
+    if (c->s_side) hipStreamDestroy(c->s_side);
     hipFree(c->d_clk);
     hipFree(c->d_intra);
     if (c->xev) hipEventDestroy(c->xev);
@@ -907,6 +1019,7 @@ int vcs_set_ref(vcs_ctx *c, const uint8_t *ref) {
     int rc = use(c);
     if (rc) return rc;
     if (!ref) return fail(c, VCS_E_ARG, "null reference frame");
+    if ((rc = bits_tables_stale(c, c->d_ref))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->d_ref, ref, c->F, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->ref_valid = true;
@@ -1402,7 +1515,7 @@ int vcs_dev_ptr(vcs_ctx *c, int which, void **ptr, size_t *bytes) {
 
 int vcs_ref_written(vcs_ctx *c) {
     int rc = use(c);
-    if (rc) return rc;
+    if (rc || (rc = bits_tables_stale(c, c->d_ref))) return rc;
     c->ref_valid = true;
     c->sums_valid = false;
     return VCS_OK;
@@ -1414,7 +1527,33 @@ int vcs_ref_swap(vcs_ctx *c) {
     std::swap(c->d_ref, c->d_ref_alt);
     c->ref_valid = true;
     c->sums_valid = false;
+    c->next_ready = false;
     return VCS_OK;
+}
+
+int vcs_ref_next_ready(vcs_ctx *c, void *written_on_stream) {
+    int rc = use(c);
+    if (rc || (rc = ensure_ref_alt(c))) return rc;
+    if (written_on_stream && (hipStream_t)written_on_stream != c->stream) {
+        if (!c->ev_next) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->ev_next, (hipStream_t)written_on_stream));
+    } else if (c->ev_next) {
+        hipEventDestroy(c->ev_next);   // written in the context's own stream order: nothing else to wait for
+        c->ev_next = nullptr;
+    }
+    c->next_ready = true;
+    return VCS_OK;
+}
+
+int vcs_set_ref_next(vcs_ctx *c, const uint8_t *ref) {
+    int rc = use(c);
+    if (rc || (rc = ensure_ref_alt(c))) return rc;
+    if (!ref) return fail(c, VCS_E_ARG, "null reference frame");
+    // (a shadow build still reading the buffer's previous content -- the caller skipped a swap -- first)
+    if ((rc = bits_tables_stale(c, c->d_ref_alt))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_ref_alt, ref, c->F, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // the host buffer is the caller's again
+    return vcs_ref_next_ready(c, nullptr);
 }
 
 // ---- intra prediction -----------------------------------------

@@ -100,6 +100,8 @@ SIGNATURES = {
     "vcs_stream_signal": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_handle": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_void_p)]),
     "vcs_ref_swap": (ctypes.c_int, [_c_ctx]),
+    "vcs_ref_next_ready": (ctypes.c_int, [_c_ctx, ctypes.c_void_p]),
+    "vcs_set_ref_next": (ctypes.c_int, [_c_ctx, ctypes.c_void_p]),
     "vcs_timing_enable": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
     "vcs_timing_reset": (ctypes.c_int, [_c_ctx]),
     "vcs_timing": (ctypes.c_int, [_c_ctx, _f64p, _u64p, ctypes.c_int]),
@@ -547,6 +549,16 @@ class Context:
     def ref_swap(self):
         """Exchange the current and the alternate reference buffer (dev_ptr 0 <-> 3)."""
         self._ck(self._lib.vcs_ref_swap(self._h))
+
+    def ref_next_ready(self, written_on_stream=0):
+        """The alternate reference buffer (dev_ptr 3) holds the next GOP's I frame: its search tables are cut
+        beside the search kernel of the GOP encoded next; `ref_swap` then finds them ready."""
+        self._ck(self._lib.vcs_ref_next_ready(self._h, ctypes.c_void_p(int(written_on_stream) or None)))
+
+    def set_ref_next(self, ref):
+        """Upload the NEXT GOP's I frame into the alternate buffer and declare it ready (see ref_next_ready)."""
+        ref = _frame(ref, self.shape, "reference frame")
+        self._ck(self._lib.vcs_set_ref_next(self._h, ref.ctypes.data_as(_u8p)))
 
     def stream_wait(self, foreign_stream):
         """Our stream waits for `foreign_stream` (a hipStream_t as int; 0 = default)."""
