@@ -125,19 +125,27 @@ def parity_columns(ctx, ref, frames, mv, slot0, bs):
 def host_path(H, W, bs, ref, frames, device, n_frames=48):
     """SURVEY 8d "separately including H2D/D2H": the reference's own driving loop
     (main.py:34-43: one Encoder.encode_frame per captured frame) through the drop-in
-    Encoder, frames produced into page-locked buffers, planes left in HBM."""
+    Encoder.  Three ways: `default` = what an unchanged main.py gets (no keyword, no environment
+    variable, frames in ordinary pageable arrays, the whole I frame hashed per P frame);
+    `pipelined` = the frame feeder (resident=True, frames produced into its page-locked ring);
+    `synchronous` = the feeder with one host synchronisation per frame."""
     import encoder as E
     import vcs_hip
     from _runtime import release_contexts
     pattern = ["I"] + ["P"] * 29
     res = {}
-    for label, kw in (("pipelined", {}), ("synchronous", {"async_slots": 0})):
+    saved_env = os.environ.pop("VCS_RESIDENT", None)
+    for label, kw, pinned in (("default", {}, False), ("pipelined", {"resident": True}, True),
+                              ("synchronous", {"resident": True, "async_slots": 0}, True)):
         enc = E.Encoder(pattern=pattern, shape=[H, W], block_size=bs, with_DCT=True, dct_block_size=8,
-                        device=device, resident=True, **kw)
+                        device=device, **kw)
         sink = io.StringIO()
-        iframe = vcs_hip.pinned_empty((H, W, 3))
-        iframe[...] = ref
-        ring = [iframe] + [enc.next_buffer() for _ in range(5)]   # the feeder's page-locked ring
+        if pinned:
+            iframe = vcs_hip.pinned_empty((H, W, 3))
+            ring = [iframe] + [enc.next_buffer() for _ in range(5)]   # the feeder's page-locked ring
+        else:
+            ring = [np.empty((H, W, 3), np.uint8) for _ in range(6)]   # pageable, as cap.read() returns them
+        ring[0][...] = ref
         for k in range(1, 6):
             ring[k][...] = frames[k % len(frames)]
 
@@ -170,13 +178,19 @@ def host_path(H, W, bs, ref, frames, device, n_frames=48):
                       "mb_per_ms": round(N / per_frame / 1e3, 1)}
         res[label]["last_frame_blocks"] = len(enc.encoded_frames[-1].mv)
         del enc
-    release_contexts()
+        release_contexts()
+    if saved_env is not None:
+        os.environ["VCS_RESIDENT"] = saved_env
     out = dict(res["pipelined"])
     out["synchronous_encode_frame_ms"] = res["synchronous"]["encode_frame_ms"]
+    out["default_mode"] = dict(res["default"], what=(
+        "Encoder(pattern, shape, block_size, with_DCT) exactly as main.py:29-43 builds and drives it: no keyword "
+        "beyond dct_block_size, no environment variable, pageable frames, the I frame hashed per P frame "
+        "(encoder.py:42's aliasing); planes stay in HBM behind Frame.r, vectors arrive lazily"))
     out["what"] = ("drop-in Encoder(resident=True).encode_frame per 1080p frame from page-locked "
                    "buffers, H2D of the frame and D2H of its vectors included, planes stay in HBM; "
                    "%d frames; with_producer_copy_ms adds the producer's own 6 MB write into the "
-                   "page-locked buffer before every call" % n_frames)
+                   "page-locked buffer before every call; default_mode: see there" % n_frames)
     return out
 
 
@@ -228,6 +242,58 @@ def coeff_modes(H, W, bs, ref, frames, device, steps=8):
                          "enc_tail_gbs": round(alg / (tail * 1e-3) / 1e9, 1)}
     out["note"] = "two resident GOP copies in turn; float64 (the reference's type) is the headline"
     return out
+
+
+def reference_default_point(H, W, ref, frames, device, steps=10, sets=3):
+    """The reference's own default operating point (main.py:15: block_size = 8 -> 8x8 motion blocks, +-16 px,
+    stride round(8 / 3) = 3, motion.py:18 / :132) on the same GOP: the whole step (k_bits_ref8, k_bits_cur8,
+    k_me8b, k_fdct), `sets` resident copies in turn like the headline, vectors of three frames against the
+    oracle outside the timed region."""
+    import vcs_hip
+    from oracle import oracle
+    bs, n = 8, len(frames)
+    N = (H // bs) * (W // bs)
+    with vcs_hip.Context(H, W, bs, 8, device=device) as c:
+        c.set_ref(ref)
+        c.gop_reserve(sets * n)
+        for s in range(sets):
+            c.gop_upload(s * n, frames)
+        for k in range(sets):
+            c.ref_written()
+            c.gop_encode(k * n, n)
+        c.sync()
+        t_end = time.perf_counter() + float(os.environ.get("VCS_BENCH_CONDITION_MS", "250")) / 1e3
+        k = 0
+        while time.perf_counter() < t_end:      # the same clock conditioning as the headline
+            c.ref_written()
+            c.gop_encode((k % sets) * n, n)
+            k += 1
+            if k % 16 == 0:
+                c.sync()
+        c.sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            c.ref_written()
+            c.gop_encode((k % sets) * n, n)
+        c.sync()
+        dt = (time.perf_counter() - t0) / steps
+        last = ((steps - 1) % sets) * n
+        mv, ns = c.gop_get_mv(last, n)
+        c.timing_enable(True)
+        c.timing_reset()
+        for k in range(steps):
+            c.ref_written()
+            c.gop_encode((k % sets) * n, n)
+        c.sync()
+        ms, _ = c.timing()
+    cmp_frames = sorted({0, n // 2, n - 1})
+    exact = sum(int(np.array_equal(mv[f], oracle.me(frames[f], ref, bs)[0])) for f in cmp_frames)
+    return {"what": "main.py:15's operating point: 8x8 motion blocks, +-16 px, stride 3 (motion.py:18, :132), 8x8 DCT QF 50, "
+                    "float64 planes; %d P frames per step, %d resident copies in turn" % (n, sets),
+            "value": round(n * N / dt / 1e3, 1), "unit": "8x8 blocks/ms", "ms_per_step": round(dt * 1e3, 4),
+            "blocks_per_frame": N, "searched_block_fraction": round(1.0 - float(ns.sum()) / (n * N), 4),
+            "kernel_ms_per_step": kernel_ms(ms, steps),
+            "mv_exact_fraction": exact / len(cmp_frames), "frames_compared": len(cmp_frames)}
 
 
 class _FileSync:
@@ -350,6 +416,47 @@ class _ReplicaShards:
         self.fs.close()
 
 
+def group_enqueue_probe(H, W, bs, ref, frames, device, steps=12):
+    """Host time to enqueue one GOP step through the group layer for 1, 2 and 3 contexts on ONE device
+    (same-device groups run the multi-GPU schedule with device copies for collectives): what a
+    single-process `--gpus N` job pays per step on the host, by number of local shards.  The shards are
+    enqueued by one thread each inside vcs_group_encode (VCS_GROUP_THREADS=0: all from the caller)."""
+    import vcs_hip
+    out = {}
+    n_total = len(frames)
+    for n_ctx in (1, 2, 3):
+        ctxs = [vcs_hip.Context(H, W, bs, 8, device=device) for _ in range(n_ctx)]
+        g = vcs_hip.Group(ctxs)
+        try:
+            g.layout(n_total)
+            for i in range(g.n_local):
+                first, count = g.shard(i)
+                if count:
+                    g.upload(first, frames[first:first + count])
+            g.set_ref(ref)
+            for _ in range(3):
+                g.encode()
+                g.prefetch_ref()
+            g.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.encode()
+                g.prefetch_ref()
+            t_enq = time.perf_counter() - t0
+            g.sync()
+            dt = time.perf_counter() - t0
+            out[str(n_ctx)] = {"host_enqueue_ms_per_step": round(t_enq / steps * 1e3, 4),
+                               "ms_per_step": round(dt / steps * 1e3, 4)}
+        finally:
+            g.close()
+            for c in ctxs:
+                c.close()
+    out["what"] = ("the %d P frames of the GOP split over n same-device contexts (keys: n); enqueue = vcs_group_encode + "
+                   "vcs_group_prefetch_ref per step from Python; threads per shard: %s"
+                   % (n_total, "off" if os.environ.get("VCS_GROUP_THREADS") == "0" else "on"))
+    return out
+
+
 def intra_mode(args, real_stdout):
     """BASELINE config 5: intramodes.py 4x4 intra prediction + the 4x4 core
     transform on a 1080p I frame (resized to multiples of 16 as intraframe.py:324 does: 1920 x
@@ -435,9 +542,10 @@ def main():
     n_gpus = world if world > 1 else n_local
     use_group = args.group or n_gpus > 1
     args.with_decode = args.with_decode or not args.no_extras   # second line of SURVEY 8d
-    # VCS_BENCH_REF_PIPELINE=0: every step declares its I frame only when it starts (round 3's loop): the
-    # per-reference tables are then cut in front of each GOP's search instead of beside the previous one's
-    pipelined_ref = os.environ.get("VCS_BENCH_REF_PIPELINE", "1") != "0" and not args.same_ref
+    # VCS_BENCH_REF_PIPELINE=1: the next GOP's I frame is declared while this GOP is encoded (vcs_ref_next_ready)
+    # and its search tables are cut beside this GOP's search kernel instead of in front of the next one's.
+    # Measured break-even at best (profiles/r04/experiments.txt): off by default.
+    pipelined_ref = os.environ.get("VCS_BENCH_REF_PIPELINE", "0") == "1" and not args.same_ref
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a
     # version banner), so file descriptor 1 is pointed at stderr for the whole run and the
     # line goes to a private copy of the original stdout.
@@ -642,13 +750,20 @@ def main():
         me_name = (("k_me16b" if bs == 16 else "k_me8b") if bits else "k_me16g" if bs == 16 and n0 >= 4
                    else "k_me16r/k_me16" if bs == 16 else "k_me8" if bs == 8 else "k_me_generic")
         names = {vcs_hip.T_ME: me_name, vcs_hip.T_ENC_TAIL: "k_fdct<residual>"}
+        # roofline.traffic: PMC bytes from profiles/hbm_traffic.json, but only if that file was collected with
+        # THIS build of the library (vcs_build_id: a hash of the kernel sources and flags); else null + stale
         tj = {}
         traffic = {}
+        traffic_stale = None
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "hbm_traffic.json")))
             wl = tj["workload"]
             if (wl["H"], wl["W"], wl["frames_per_launch"], wl["me_bs"]) == (H, W, n0, bs):
-                traffic = {k: v["hbm_bytes_corrected"] for k, v in tj["kernels"].items()}
+                if tj.get("build_id") == vcs_hip.build_id():
+                    traffic = {k: v["hbm_bytes_corrected"] for k, v in tj["kernels"].items()}
+                else:
+                    traffic_stale = {"profiles_build_id": tj.get("build_id"), "library_build_id": vcs_hip.build_id()}
+                    tj = {}
         except (OSError, KeyError, ValueError):
             pass
 
@@ -660,6 +775,8 @@ def main():
                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                  "traffic": traffic.get(names[slot]),
                  "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_ms, 4)}
+            if traffic_stale:
+                r["traffic_stale"] = True
             if slot == vcs_hip.T_ME and bits:
                 # the search's algorithmic bytes (2F + 4N per frame) are the whole stage's: k_bits_cur
                 # (current blocks -> bit planes, static test) runs in front of k_me16b
@@ -714,6 +831,8 @@ def main():
                                           "dispatch packets (hipExtLaunchKernelGGL); the events cost time, so the "
                                           "headline pass runs without them" % args.steps,
                                   "ms_per_step_with_events": round(dt_ev / args.steps * 1e3, 4)},
+            "build_id": vcs_hip.build_id(),
+            **({"traffic_stale": traffic_stale} if traffic_stale else {}),
             "roofline": roof(dom),
             "roofline_second_kernel": roof(other),
             # the whole step against HBM: 10F + 4N algorithmic bytes per P frame on GPU 0
@@ -830,11 +949,26 @@ def main():
                 out["coeff_modes"] = coeff_modes(H, W, bs, ref, local_frames[0], devices[0])
             except Exception as e:
                 out["coeff_modes"] = {"error": repr(e)}
+            try:
+                out["reference_default_point_bs8"] = reference_default_point(H, W, ref, local_frames[0], devices[0])
+            except Exception as e:
+                out["reference_default_point_bs8"] = {"error": repr(e)}
+        if args.group and n_gpus == 1 and not args.strong and not launched:
+            try:
+                out["group_enqueue_by_local_shards"] = group_enqueue_probe(H, W, bs, ref, local_frames[0], devices[0])
+            except Exception as e:
+                out["group_enqueue_by_local_shards"] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if state_stuck:        # a bring-up thread is still inside RCCL: it cannot be joined
-        sys.stderr.flush()
-        os._exit(0)
+    # The no-collective fall-back is not a measurement of the multi-GPU path: the line above says so
+    # (`degraded`, `scaling: null`) and the process leaves with status 3, so that a driver that only looks at
+    # exit codes sees it too.  A bring-up thread still inside RCCL cannot be joined: os._exit then.
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if state_stuck:
+        os._exit(3 if rccl_failed else 0)
+    if rccl_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -64,6 +64,15 @@ typedef struct vcs_ctx vcs_ctx;
 
 /* ---- library / device -------------------------------------------------- */
 int vcs_abi_version(void);
+/* Identity of the build: the first 16 hex digits of sha256 over the kernel and
+ * ABI sources (csrc/ Makefile order) and the extra compiler flags, stamped by
+ * the Makefile.  profiles/hbm_traffic.json carries the id of the library its
+ * counters were collected with; bench.py reports `traffic` only when the two
+ * agree (no reference counterpart: measurement plumbing).                    */
+const char *vcs_build_id(void);
+/* 1 if the library was built with any VCS_EXP_* experiment switch (timing
+ * probes, variants that compute wrong results on purpose), else 0.           */
+int vcs_experiment_build(void);
 int vcs_device_count(int *n);
 /* Page-locked host memory for frames and planes (hipHostMalloc): buffers handed to the
  * entry points below are copied by DMA at PCIe rate when they live in such memory and

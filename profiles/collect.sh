@@ -25,7 +25,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" \
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc_$name -- python3 $B > $out/pmc_$name.log 2>&1
 done
 python3 - $out <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
 out = sys.argv[1]
 res = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
 for f in glob.glob(out + '/pmc_*/*/*_counter_collection.csv'):
@@ -37,6 +37,10 @@ for k, v in res.items():
     if 'rocclr' in k: continue
     summary[k] = {c: x / len(disp[(k, c)]) for c, x in v.items()}
     summary[k]['dispatches_sampled'] = max(len(disp[(k, c)]) for c in v)
+# the library these counters belong to (bench.py reports roofline.traffic only for this build)
+sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '.'), 'vcs-h264_amd'))
+import vcs_hip
+summary['build_id'] = vcs_hip.build_id()
 json.dump(summary, open(out + '/pmc_per_dispatch.json', 'w'), indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1, sort_keys=True))
 PY

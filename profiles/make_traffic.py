@@ -27,6 +27,7 @@ PMC_PREFIX = {"vcs::k_me16b": "k_me16b", "vcs::k_bits_cur": "k_bits_cur", "vcs::
 
 def main(path):
     pmc = json.load(open(path))
+    build_id = pmc.pop("build_id", None)   # vcs_build_id() of the library the counters were collected with
     kernels = {}
     for prefix, name in PMC_PREFIX.items():
         keys = [k for k in pmc if k.startswith(prefix) and "primer" not in k]
@@ -51,6 +52,7 @@ def main(path):
         }
     out = {
         "workload": {"H": H, "W": W, "frames_per_launch": FRAMES, "me_bs": BS},
+        "build_id": build_id,
         "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of "
                "`bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras` (profiles/collect.sh; the bench rotates "
                "through three resident copies of the GOP, so nothing is re-read from the Infinity Cache); KB per "

@@ -128,10 +128,12 @@ def test_config4_4k_per_rank_gop_share(vh, oracle):
             assert np.array_equal(c.gop_get_decoded(k), oracle.decode_p(omv, oplanes, ref, 16)), k
 
 
-def test_config4_4k_two_gpu_share_banded_bitplane_search(vh, oracle):
+def test_config4_4k_two_gpu_share_bitplane_search(vh, oracle):
     """C4 on two GPUs: 15 of the 29 P frames of a 3840x2160 GOP on rank 0 -- enough frames for the
-    bit-plane search, whose chunk table goes in four bands of 60 block columns at this width, while
-    the tail runs in cache-sized sub-batches; vectors of every frame, planes of three, vs the oracle."""
+    bit-plane search (one 497 MB chunk table at this width: kBitsBandBytes = 1 GiB; the banded form is
+    covered by the VCS_BITS_BAND_KB child of test_forced_kernel_variants_subprocess on small frames and by
+    test_banded_chunk_table_on_a_real_4k_frame below), while the tail runs in cache-sized sub-batches;
+    vectors of every frame, planes of three, vs the oracle."""
     from gop import shard_frames
     from synth import synth_gop
     H, W = 2160, 3840
@@ -154,6 +156,21 @@ def test_config4_4k_two_gpu_share_banded_bitplane_search(vh, oracle):
 
 
 # ------------------------------------------------------------ ADVICE (round 1) ----
+def test_banded_chunk_table_on_a_real_4k_frame(oracle):
+    """The same 4K share with the chunk table forced into four bands of ~60 block columns (VCS_BITS_BAND_KB =
+    128 MB; per launch: k_bits_cur once, then k_bits_ref + k_me16b per band, the prefetch on the last band) --
+    the path frames beyond 1 GiB of table take.  One child process (the band size is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, VCS_ORACLE_MEMO=oracle._root, VCS_ME16_BITS="2", VCS_BITS_BAND_KB=str(128 * 1024))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_configs.py"), "-m", "gpu", "-x", "-q",
+                        "-k", "config4_4k_two_gpu_share", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
+
+
 def test_similarity_threshold_survives_q_pushes(vh, oracle, capsys):
     """motion.SIMILARITY_THRESHOLD edited by hand (as the reference expects) must
     survive the Q / coeff_mode pushes of Encoder, Decoder and DCTCompressor on the

@@ -91,15 +91,25 @@ def test_golden_dct_small(vh, qf):
         assert np.array_equal(c.decompress(g["planes_q%d" % qf]), g["dec_q%d" % qf])
 
 
-def test_golden_codec_dropin(vh, capsys):
-    """The reference's own call sequence (main.py:29-50) on the drop-in classes."""
+@pytest.mark.parametrize("resident_env", [None, "0"])
+def test_golden_codec_dropin(vh, capsys, monkeypatch, resident_env):
+    """The reference's own call sequence (main.py:29-50) on the drop-in classes, replaying a run of the
+    reference's Encoder / Decoder.  Default (no keyword, no environment variable: what an unchanged main.py
+    gets): Frame.mv / Frame.c are list-like views, Frame.r a list-like view of planes kept in HBM -- every
+    access main.py:48-50 and decoder.py:52-69 make of them must give the reference's values.
+    VCS_RESIDENT=0: real Python lists and NumPy planes, type for type as upstream."""
     import encoder as E
     import decoder as D
+    if resident_env is None:
+        monkeypatch.delenv("VCS_RESIDENT", raising=False)
+    else:
+        monkeypatch.setenv("VCS_RESIDENT", resident_env)
     g = load_golden("codec_small.npz")
     frames = g["frames"]
     H, W = frames.shape[1:3]
     for with_dct, tag in ((True, "dct"), (False, "raw")):
         enc = E.Encoder(pattern=["I", "P", "P"], shape=[H, W], block_size=8, with_DCT=with_dct)
+        assert enc.resident == (resident_env is None)
         for n in range(len(frames)):
             enc.encode_frame(frames[n], n)
         assert [f.t for f in enc.encoded_frames] == ["I", "P", "P", "I", "P"]
@@ -112,11 +122,21 @@ def test_golden_codec_dropin(vh, capsys):
             assert fr.i == n and fr.ref_i == int(g["%s_refi_%d" % (tag, n)])
             if fr.t != "P":
                 continue
-            assert isinstance(fr.mv, list) and isinstance(fr.mv[0][0], int)
-            assert np.array_equal(np.array(fr.mv), g["%s_mv_%d" % (tag, n)])
+            want_mv = g["%s_mv_%d" % (tag, n)]
+            if resident_env == "0":
+                assert isinstance(fr.mv, list) and isinstance(fr.c, list)
+            # what a list of [dx, dy] pairs offers: len, indexing down to Python ints, iteration, ==
+            assert len(fr.mv) == len(want_mv) == len(fr.c)
+            assert isinstance(fr.mv[0][0], int) and isinstance(fr.c[0][1], int)
+            assert fr.mv[3] == want_mv[3].tolist() and fr.mv == want_mv.tolist()
+            assert [list(p) for p in fr.mv] == want_mv.tolist()
+            assert np.array_equal(np.array(fr.mv), want_mv)
             if with_dct:
-                assert isinstance(fr.r, list) and len(fr.r) == 3
-                assert np.array_equal(np.stack(fr.r), g["dct_r_%d" % n])
+                if resident_env == "0":
+                    assert isinstance(fr.r, list)
+                assert len(fr.r) == 3
+                assert np.array_equal(np.stack(list(fr.r)), g["dct_r_%d" % n])
+                assert np.array_equal(fr.r[1], g["dct_r_%d" % n][1])
             else:
                 assert np.array_equal(fr.r, g["raw_r_%d" % n])
             assert np.array_equal(dec._reconstruct_P_frame(fr, True), g["%s_full_%d" % (tag, n)])
@@ -125,6 +145,29 @@ def test_golden_codec_dropin(vh, capsys):
         dec.reconstruct_video(with_residuals=True)
         assert len(sink) == 5
         assert np.array_equal(sink[4], g["%s_full_4" % tag])
+    capsys.readouterr()
+
+
+def test_default_mode_honours_the_aliased_i_frame(vh, oracle, capsys, monkeypatch):
+    """encoder.py:42 stores the caller's I-frame ARRAY, so an in-place edit between two P frames reaches the
+    second one.  The default mode (planes in HBM, pipelined) keeps that without any call: the whole I frame
+    is hashed per P frame."""
+    import encoder as E
+    from synth import synth_v1
+    monkeypatch.delenv("VCS_RESIDENT", raising=False)
+    ref, cur = synth_v1(144, 176, seed=77)
+    ref = ref.copy()
+    enc = E.Encoder(pattern=["I", "P", "P"], shape=[144, 176], block_size=16, with_DCT=True, dct_block_size=8)
+    enc.encode_frame(ref, 0)
+    enc.encode_frame(cur, 1)
+    want1 = oracle.me(cur, ref, 16)[0]
+    assert np.array_equal(np.asarray(enc.encoded_frames[1].mv), want1)
+    ref[40:90, 30:120] = np.roll(ref[40:90, 30:120], 7, axis=1)      # edit the I frame the encoder aliases
+    enc.encode_frame(cur, 2)
+    want2 = oracle.me(cur, ref, 16)[0]
+    assert not np.array_equal(want1, want2)
+    assert np.array_equal(np.asarray(enc.encoded_frames[2].mv), want2)
+    assert np.array_equal(np.stack(list(enc.encoded_frames[2].r)), oracle.encode_p(cur, ref, 16)[1])
     capsys.readouterr()
 
 
@@ -813,7 +856,9 @@ def test_forced_kernel_variants_subprocess(oracle):
                        ({"VCS_TAIL_MAP": "2"}, dct + " or gop_1080p_vs_oracle"),
                        # Infinity Cache prefetch as a separate pass / off (default: inside the search kernel)
                        ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "2"}, "gop_1080p_vs_oracle or gop_matches_single"),
-                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "0"}, "gop_1080p_vs_oracle or gop_matches_single"))
+                       ({"VCS_ME16_BITS": "0", "VCS_ME16_ROLL": "2", "VCS_L3_PREFETCH": "0"}, "gop_1080p_vs_oracle or gop_matches_single"),
+                       # the bit-plane search's scratch cannot be allocated: the shared-window kernels serve the batch
+                       ({"VCS_TEST_BITS_NOMEM": "1"}, "bitplane or gop_1080p_vs_oracle or golden_me_small or next_reference"))
 
     def child(v):
         env_add, k = v
@@ -821,12 +866,19 @@ def test_forced_kernel_variants_subprocess(oracle):
         return env_add, subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"),
                                         "-m", "gpu", "-x", "-q", "-k", k, "-p", "no:cacheprovider"],
                                        env=env, capture_output=True, text=True, timeout=900)
-    # three children at a time (a child is mostly start-up: interpreter, library, the first launches);
-    # with this process that is four on the card, inside the box's limit of six
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=3) as pool:
-        for env_add, r in pool.map(child, variants):
+    # One child at a time: with the oracle's results memoised on disk a child is mostly start-up, and a fault
+    # or a hang is then one variant's, by name.  VCS_TEST_PARALLEL=n runs n at a time (a box allows six
+    # processes on the card; this one is the first).
+    workers = max(1, min(4, int(os.environ.get("VCS_TEST_PARALLEL", "1"))))
+    if workers == 1:
+        for v in variants:
+            env_add, r = child(v)
             assert r.returncode == 0, (env_add, r.stdout[-1500:], r.stderr[-500:])
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            for env_add, r in pool.map(child, variants):
+                assert r.returncode == 0, (env_add, r.stdout[-1500:], r.stderr[-500:])
 
 
 @pytest.mark.parametrize("env", [{"VCS_ME16_BITS": "2", "VCS_ME8_BITS": "2"}, {}, {"VCS_ME16_BITS": "0", "VCS_ME8_BITS": "0"}])

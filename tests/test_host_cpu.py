@@ -39,6 +39,24 @@ def test_library_exports_every_declared_symbol(vh):
     assert vh.load().vcs_abi_version() == 2
 
 
+def test_library_is_the_tree_and_no_experiment_build(vh):
+    """The shipped library was built from the sources in the tree (vcs_build_id = hash of csrc/ + flags: what
+    bench.py ties profiles/hbm_traffic.json to) and without any VCS_EXP_* experiment switch; every such switch
+    in csrc/ is fenced by the umbrella macro in vcs_common.hpp."""
+    lib = vh.load()
+    assert lib.vcs_experiment_build() == 0
+    assert vh.build_id() == vh.source_build_id(), "libvcs_hip.so is older than csrc/: rebuild (python __graft_entry__.py build)"
+    csrc = os.path.join(REPO, "vcs-h264_amd", "csrc")
+    common = open(os.path.join(csrc, "vcs_common.hpp")).read()
+    fenced = set(re.findall(r"defined\((VCS_EXP_[A-Z0-9_]+)\)", common))
+    used = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hpp", ".hip")):
+            for m in re.finditer(r"^\s*#\s*(?:ifdef|ifndef|if|elif)\b.*?\b(VCS_EXP_[A-Z0-9_]+)", open(os.path.join(csrc, f)).read(), re.M):
+                used.add(m.group(1))
+    assert used <= fenced, "experiment switches outside the umbrella: %s" % sorted(used - fenced)
+
+
 def test_host_only_entry_points_match_golden(vh):
     g = load_golden("dct_small.npz")
     assert np.array_equal(vh.dct_matrix(), g["dctmat"])  # DCTcompressor.py:124-133

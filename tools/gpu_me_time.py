@@ -30,8 +30,8 @@ ref, frames = synth_gop(H, W, n, seed=1234, first=1)
 frames = np.ascontiguousarray(frames)
 if a.static > 0:
     frames[:, :, : int(W * a.static)] = ref[:, : int(W * a.static)]
-# VCS_BENCH_REF_PIPELINE=0: the I frame is declared when its GOP starts (tables cut in front of the search)
-pipe = os.environ.get("VCS_BENCH_REF_PIPELINE", "1") != "0"
+# VCS_BENCH_REF_PIPELINE=1: the next I frame is declared early and its tables are cut beside this GOP's search
+pipe = os.environ.get("VCS_BENCH_REF_PIPELINE", "0") == "1"
 
 
 def new_gop(c):

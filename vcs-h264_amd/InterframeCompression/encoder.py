@@ -8,12 +8,22 @@ separate host round trips; the stored Frame is identical to the reference's.
 Extension (keyword-only): `dct_block_size` -- the reference hands ONE
 block_size to both MotionProcessor and DCTCompressor (encoder.py:16-18), so
 with_DCT only works at 8; pass dct_block_size=8 to compose e.g. 16x16 motion
-blocks with the 8x8 DCT (the BASELINE workload).  `resident=True` (or the
-environment variable VCS_RESIDENT=1, so that an unchanged main.py can opt in)
-leaves the coefficient planes of Frame.r in HBM: Frame.r is then a list-like
-view that downloads on first access, and the drop-in Decoder decodes straight
-from HBM -- the 8x-frame-size planes never cross PCIe; Frame.mv and Frame.c are
-then list-like views of integer arrays (frame.RowList) instead of N Python lists.
+blocks with the 8x8 DCT (the BASELINE workload).
+
+Where the results live.  By DEFAULT (what an unchanged main.py gets) the
+coefficient planes of Frame.r stay in HBM: Frame.r is a list-like view of three
+planes that downloads on first access, the drop-in Decoder decodes straight
+from HBM -- the 8x-frame-size planes never cross PCIe (50 MB of float64 per
+1080p frame: 4.7 ms, against 0.3 ms for everything else) --, Frame.mv and
+Frame.c are list-like views of integer arrays (frame.RowList: len, indexing,
+iteration, ==, tolist) instead of N Python lists, and encode_frame returns once
+the frame is enqueued (Frame.mv waits on first access).  main.py:48-50 and
+decoder.py:52-69 use nothing else of them.  The reference's aliasing of the
+caller's I frame (encoder.py:42) holds: the whole I frame is hashed per P frame.
+VCS_RESIDENT=0 (or resident=False) restores real `list` objects and NumPy planes
+per frame, downloaded on the spot.  resident=True (explicit) additionally
+replaces the per-frame hash by a generation (this encoder, I frame index):
+a caller that edits an I frame in place then calls invalidate_ref().
 """
 import itertools
 import os
@@ -43,7 +53,9 @@ class Encoder:
         self.DCTCompressor = DCTCompressor(
             block_size=block_size if dct_block_size is None else dct_block_size, device=device)
         self.with_DCT = with_DCT
-        self.resident = (os.environ.get("VCS_RESIDENT") == "1") if resident is None else bool(resident)
+        self.resident = (os.environ.get("VCS_RESIDENT", "1") != "0") if resident is None else bool(resident)
+        # explicit resident=True: the caller vouches for its I frames (generation instead of a hash per P frame)
+        self._trust_ref = resident is True or (resident is None and os.environ.get("VCS_RESIDENT") == "1")
         # HBM budget of the planes kept behind Frame.r (49.8 MB per 1080p frame): past it the
         # oldest frames' planes are spilled to host memory (VCS_RESIDENT_MAX_BYTES, default 64 GiB)
         self.resident_max_bytes = int(os.environ.get("VCS_RESIDENT_MAX_BYTES", str(64 << 30)))
@@ -75,9 +87,9 @@ class Encoder:
         flush_async(self.MotionProcessor._ctx())
 
     def invalidate_ref(self):
-        """Call after editing an I frame IN PLACE when resident=True: the next P frame then
-        re-uploads its reference (the default mode hashes the whole I frame per P frame and
-        needs no such call)."""
+        """Call after editing an I frame IN PLACE when resident=True was asked for explicitly: the
+        next P frame then re-uploads its reference (every other mode hashes the whole I frame per P
+        frame and needs no such call)."""
         invalidate_ref(self.MotionProcessor._ctx())
 
     def encode_frame(self, input_frame, frame_num):
@@ -109,10 +121,10 @@ class Encoder:
         if self.with_DCT:
             dc._check(mp.shape[0], mp.shape[1])
         ctx = mp._ctx()
-        # resident mode: the I frame is identified by (this encoder's serial, its index) -- no per-frame
-        # hashing of 6-25 MB; default mode: full hash (the caller's array is aliased, encoder.py:42)
+        # explicit resident mode: the I frame is identified by (this encoder's serial, its index) -- no
+        # per-frame hashing of 6-25 MB; otherwise: full hash (the caller's array is aliased, encoder.py:42)
         ensure_ref(ctx, _as_frame(ref, mp.shape, "ref_frame"),
-                   generation=(self._serial, ref_idx) if self.resident else None)
+                   generation=(self._serial, ref_idx) if self._trust_ref else None)
         if self.with_DCT:
             ensure_q(ctx, dc.Q, dc.coeff_mode)
         keep = self.with_DCT and self.resident

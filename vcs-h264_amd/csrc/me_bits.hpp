@@ -141,7 +141,7 @@ constexpr int kBitsCurThreads = kBitsCurBlocks * 8;
 #endif
 // frames per thread: a thread keeps its co-located reference pieces (and their byte sum) in registers for
 // kBitsCurFpt frames of the batch -- read per frame they are L2 hits, but half of the kernel's loads
-// (0.022 of its 0.064 ms at 29 x 1080p, VCS_EXP_BITS_NOREF)
+// (0.022 of its 0.064 ms at 29 x 1080p, measured with a build that skipped them)
 constexpr int kBitsCurFpt = VCS_BITS_CUR_FPT;
 __global__ __launch_bounds__(kBitsCurThreads) void k_bits_cur(const uint8_t *__restrict__ curs, size_t cur_stride,
                                                   const uint8_t *__restrict__ ref, Geom g, int n_frames,
@@ -830,6 +830,13 @@ inline bool me_bits_worthwhile(const Geom &g, int n) {
     const int m = me_bits_mode();
     if (m == 0 || !me_fast_supported(g)) return false;
     if ((long long)g.N * n * kBitsBlk > 0x7FFFFFFFll * 4) return false;
+    // the unit decode divides by multiply-high (div_magic: exact while x * d < 2^32): unit < ceil(columns / 8) *
+    // per_col is divided by per_col = nby * groups -- beyond that (1080p: ~2,000 frames per launch) the
+    // shared-window kernels take the batch
+    {
+        const unsigned long long per_col = (unsigned long long)g.nby * (unsigned long long)((n + kBitsNF - 1) / kBitsNF);
+        if ((unsigned long long)((me_bits_band_cols(g) + 7) / 8) * per_col * per_col >= (1ull << 32)) return false;
+    }
     const int need = (g.N > 16384 ? kBitsMinFramesBig : kBitsMinFrames) + 3 * (me_bits_bands(g) - 1);
     return m == 2 || n >= need;
 }

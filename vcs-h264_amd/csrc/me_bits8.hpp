@@ -363,6 +363,10 @@ inline bool me_bits8_worthwhile(const Geom &g, int n) {
     const int m = me_bits8_mode();
     if (m == 0 || !me_fast8_supported(g)) return false;
     if ((long long)g.N * n * kBits8Blk > 0x7FFFFFFFll * 4 || me_bits8_rtab_bytes(g) > ((size_t)1 << 30)) return false;
+    {   // div_magic in the unit decode is exact while ceil(columns / 8) * (nby * groups)^2 < 2^32 (see me_bits_worthwhile)
+        const unsigned long long per_col = (unsigned long long)g.nby * (unsigned long long)((n + kBits8NF - 1) / kBits8NF);
+        if ((unsigned long long)((g.nbx + 7) / 8) * per_col * per_col >= (1ull << 32)) return false;
+    }
     return m == 2 || n >= kBits8MinFrames;
 }
 inline int me_bits8_groups(int n) { return (n + kBits8NF - 1) / kBits8NF; }

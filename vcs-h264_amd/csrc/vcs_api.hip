@@ -426,9 +426,9 @@ int launch_me(vcs_ctx *c, const uint8_t *ref, const uint8_t *curs, size_t stride
         static const bool pf_tail_wgs = [] { const char *e = getenv("VCS_BITS_PF"); return !(e && e[0] == '0'); }();
         const bool pf = c->pf_in_search && pf_tail_wgs && (size_t)n * stride < 0xFFFFFFFFull;
         c->pf_in_search = pf;
-        // The chunk table covers one band of block columns (the whole picture at 1080p, a quarter of
-        // it at 4K): with one band it is built once per reference frame, like the sum table; with
-        // several it is rebuilt band by band in every launch (25 us per band).
+        // The chunk table covers one band of block columns (the whole picture up to 1 GiB of table: 1080p
+        // 124 MB, 4K 497 MB): with one band it is built once per reference frame, like the sum table; with
+        // several (larger frames, VCS_BITS_BAND_KB) it is rebuilt band by band in every launch.
         const bool nc = c->t_no_count;
         if (nb == 1) bits_shadow_build(c);   // the next GOP's table, beside this search
         for (int band = 0; band < nb && !rc; band++) {
@@ -782,6 +782,19 @@ int vcs_store_free(vcs_ctx *c, vcs_planes *h);
 
 int vcs_abi_version(void) { return VCS_ABI_VERSION; }
 
+#ifndef VCS_BUILD_ID
+#define VCS_BUILD_ID "unknown"
+#endif
+const char *vcs_build_id(void) { return VCS_BUILD_ID; }
+
+int vcs_experiment_build(void) {
+#ifdef VCS_EXPERIMENT_BUILD
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int vcs_host_alloc(size_t bytes, void **ptr) {
     if (!ptr || bytes == 0) return fail(nullptr, VCS_E_ARG, "null pointer or zero size");
     *ptr = nullptr;
@@ -864,6 +877,14 @@ int vcs_ctx_create(int device, int H, int W, int me_bs, int dct_bs, vcs_ctx **ou
     g.nbx = W / me_bs; g.nby = H / me_bs; g.N = g.nbx * g.nby;
     g.bs_magic = magic_u32((uint32_t)me_bs);
     g.gx_magic = magic_u32((uint32_t)((W + 63) >> 6));
+    {   // the tail kernels divide strip < groups_x * H / 8 by groups_x with one multiply-high (div_magic): exact
+        // while the product stays below 2^32 (W = 65,536 with H = 32,768 is the first frame that does not)
+        const unsigned long long gx = (unsigned long long)((W + 63) >> 6);
+        if (gx * gx * (unsigned long long)(H >> 3) >= (1ull << 32)) {
+            delete c;
+            return fail(nullptr, VCS_E_ARG, "frame %d x %d is too large for the tail kernels' strip indexing", W, H);
+        }
+    }
     g.win = 2 * me_bs;               // motion.py:18
     g.step = py_round_div3(me_bs);   // motion.py:132
     c->thresh64 = 2000;              // motion.py:8

@@ -3,6 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- experiment builds -------------------------------------------------------------------
+// The VCS_EXP_* switches (timing probes, and variants that compute WRONG results on purpose to
+// price a part of a kernel) exist only under the umbrella VCS_EXPERIMENT_BUILD, which
+// `make EXPERIMENT="-DVCS_EXP_..."` defines and vcs_experiment_build() reports: a library built
+// with any of them says so, and tests/test_host_cpu.py asserts the shipped one was not.  Every switch
+// used anywhere under csrc/ must be named here (the same test greps for strays).
+#if defined(VCS_EXP_PHASES) || defined(VCS_EXP_REF_NT) || defined(VCS_EXP_BITS_NOFOLD) || defined(VCS_EXP_NOCUR) || \
+    defined(VCS_EXP_NOWIN) || defined(VCS_EXP_NOAND) || defined(VCS_EXP_NOBARRIER) || defined(VCS_EXP_NOREDUCE) ||   \
+    defined(VCS_EXP_NOCORE) || defined(VCS_EXP_BITS_SAMEC) || defined(VCS_EXP_PLAIN_STORES) || defined(VCS_EXP_IDCT_WPE)
+#ifndef VCS_EXPERIMENT_BUILD
+#error "VCS_EXP_* switches need -DVCS_EXPERIMENT_BUILD (make EXPERIMENT=...): the library must be able to say what it is"
+#endif
+#endif
+
 namespace vcs {
 
 // Frame / block geometry shared by all kernels (filled on the host).

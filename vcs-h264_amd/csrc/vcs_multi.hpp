@@ -22,6 +22,85 @@
 #pragma once
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+// One host thread per local shard for the per-GOP enqueue (single-process groups): a shard's enqueue -- five
+// kernel launches, two copies, the event traffic -- costs ~0.06 ms of host time, and in sequence from one
+// thread eight shards cost as much host time as the GPUs need for the step.  Shard 0 is enqueued by the
+// calling thread, the others by workers that live as long as the group.  (One process per GPU -- what
+// torch.distributed.run starts -- has one shard per process and never gets here.)  VCS_GROUP_THREADS=0:
+// everything from the calling thread.
+struct GroupPool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    std::function<int(int)> job;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool stop = false;
+    std::vector<int> rc;
+
+    void start(int n) {
+        rc.assign(n, 0);
+        for (int i = 1; i < n; i++)
+            workers.emplace_back([this, i] {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::function<int(int)> j;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_go.wait(lk, [&] { return stop || gen != seen; });
+                        if (stop) return;
+                        seen = gen;
+                        j = job;
+                    }
+                    const int r = j(i);
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        rc[i] = r;
+                        if (--pending == 0) cv_done.notify_one();
+                    }
+                }
+            });
+    }
+    // job(i) for every shard i; returns the first non-zero result (by shard index)
+    int run(int n, const std::function<int(int)> &j) {
+        if (workers.empty()) {
+            for (int i = 0; i < n; i++) {
+                const int r = j(i);
+                if (r) return r;
+            }
+            return 0;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = j;
+            pending = (int)workers.size();
+            gen++;
+        }
+        cv_go.notify_all();
+        rc[0] = j(0);
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return pending == 0; });
+        }
+        for (int i = 0; i < n; i++)
+            if (rc[i]) return rc[i];
+        return 0;
+    }
+    ~GroupPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_go.notify_all();
+        for (auto &t : workers) t.join();
+    }
+};
+
 struct vcs_group {
     struct Per {
         vcs_ctx *c = nullptr;
@@ -54,6 +133,7 @@ struct vcs_group {
     bool iframe_valid = false;
     uint8_t *d_word = nullptr;    // per[0]'s device: 64 bytes for barrier / max reductions and the parameter-hash check
     std::vector<uint8_t> host;    // D2H staging of the gathered vectors
+    GroupPool *pool = nullptr;    // one enqueue thread per local shard beyond the first (single-process groups)
     std::string err;
 };
 
@@ -321,6 +401,7 @@ int vcs_group_destroy(vcs_group *g) {
     hipFree(g->d_iframe);
     hipFree(g->d_word);
     if (g->ev_iframe) hipEventDestroy(g->ev_iframe);
+    delete g->pool;
     delete g;
     return VCS_OK;
 }
@@ -552,12 +633,15 @@ int vcs_group_encode(vcs_group *g) {
     if ((rc = group_flush_gather(g))) return rc;   // the previous GOP's vectors
     if (g->gop_prefetched <= g->gop && (rc = vcs_group_prefetch_ref(g))) return rc;
     const int b = (int)(g->gop & 1);
-    for (auto &p : g->per) {
+    // one shard's enqueue; errors land in the shard's context (c->err), the caller reports the first
+    auto shard = [g, b](int i) -> int {
+        vcs_group::Per &p = g->per[i];
         vcs_ctx *c = p.c;
-        G_HIP(g, hipSetDevice(c->device));
+        c->err.clear();
+        HIP_TRY(c, hipSetDevice(c->device));
         if (p.cs != c->stream) {
-            G_HIP(g, hipStreamWaitEvent(c->stream, p.ev_ref[b], 0));  // the I frame has arrived
-            if (p.gather_rec[b]) G_HIP(g, hipStreamWaitEvent(c->stream, p.ev_gather[b], 0));  // stage[b] is free
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, p.ev_ref[b], 0));  // the I frame has arrived
+            if (p.gather_rec[b]) HIP_TRY(c, hipStreamWaitEvent(c->stream, p.ev_gather[b], 0));  // stage[b] is free
         }
         c->d_ref = p.refbuf[b];
         c->d_ref_alt = p.refbuf[b ^ 1];
@@ -566,16 +650,33 @@ int vcs_group_encode(vcs_group *g) {
         const size_t N = (size_t)c->g.N;
         if (p.count > 0) {
             const size_t s0 = (size_t)g->set * p.count;  // first slot of the set in use
-            rc = vcs_gop_encode(c, (int)s0, p.count);
-            if (rc) return gfail(g, rc, "shard %d: %s", g->rank0, c->err.c_str());
-            if ((rc = use(c))) return gfail(g, rc, "%s", c->err.c_str());  // joins CU-split streams, if any
-            if (N) G_HIP(g, hipMemcpyAsync(p.stage[b], c->g_mv + s0 * N * 2, (size_t)p.count * N * 4,
-                                           hipMemcpyDeviceToDevice, c->stream));
-            G_HIP(g, hipMemcpyAsync(p.stage[b] + (size_t)g->cmax * (N ? N : 1) * 4, c->g_ns + s0, (size_t)p.count * 4,
-                                    hipMemcpyDeviceToDevice, c->stream));
+            int rc = vcs_gop_encode(c, (int)s0, p.count);
+            if (rc || (rc = use(c))) return rc;          // (use: joins CU-split streams, if any)
+            if (N) HIP_TRY(c, hipMemcpyAsync(p.stage[b], c->g_mv + s0 * N * 2, (size_t)p.count * N * 4,
+                                             hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(p.stage[b] + (size_t)g->cmax * (N ? N : 1) * 4, c->g_ns + s0, (size_t)p.count * 4,
+                                      hipMemcpyDeviceToDevice, c->stream));
         }
-        G_HIP(g, hipEventRecord(p.ev_kern[b], c->stream));
+        HIP_TRY(c, hipEventRecord(p.ev_kern[b], c->stream));
         p.kern_rec[b] = true;
+        return VCS_OK;
+    };
+    const int n_local = (int)g->per.size();
+    if (n_local > 1 && !g->pool) {
+        static const bool threads = [] { const char *e = getenv("VCS_GROUP_THREADS"); return !(e && e[0] == '0'); }();
+        g->pool = new (std::nothrow) GroupPool();
+        if (g->pool && threads) g->pool->start(n_local);
+    }
+    if (g->pool) {
+        rc = g->pool->run(n_local, shard);
+    } else {
+        rc = VCS_OK;
+        for (int i = 0; i < n_local && !rc; i++) rc = shard(i);
+    }
+    if (rc) {
+        for (int i = 0; i < n_local; i++)
+            if (!g->per[i].c->err.empty()) return gfail(g, rc, "shard %d: %s", g->rank0 + i, g->per[i].c->err.c_str());
+        return gfail(g, rc, "a shard's enqueue failed");
     }
     // The all-gather of this GOP's vectors is enqueued LAZILY, by the next group call: a
     // vcs_group_prefetch_ref that follows puts the next I frame's broadcast IN FRONT of it on

@@ -31,6 +31,8 @@ _vp = ctypes.c_void_p
 # name -> (restype, argtypes): every symbol include/vcs_hip.h declares
 SIGNATURES = {
     "vcs_abi_version": (ctypes.c_int, []),
+    "vcs_build_id": (ctypes.c_char_p, []),
+    "vcs_experiment_build": (ctypes.c_int, []),
     "vcs_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "vcs_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
     "vcs_host_free": (ctypes.c_int, [ctypes.c_void_p]),
@@ -138,6 +140,25 @@ def load(path=None):
     if path is None:
         _LIB = lib
     return lib
+
+
+def source_build_id(extra=""):
+    """What vcs_build_id() of a library built from the sources in the tree NOW would return (csrc/Makefile:
+    sha256 over the extra flags line and the sources in the Makefile's order)."""
+    import hashlib
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    names = re.search(r"^SRC\s*:=\s*(.*)$", mk, re.M).group(1).split() + re.search(r"^HDR\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    h = hashlib.sha256((extra.strip() + "\n").encode())
+    for n in names:
+        h.update(open(os.path.join(csrc, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_id():
+    """Identity of the loaded library's sources + flags (vcs_build_id)."""
+    return load().vcs_build_id().decode()
 
 
 def device_count():
@@ -831,7 +852,7 @@ def rendezvous_unique_id(rank, world, timeout_s=180.0, tag=None, make_id=None):
         # (rank 0 itself is about to block in ncclCommInitRank).  A file nobody touches any more --
         # one left by a crashed launch -- is never accepted.
         def keep_fresh():
-            t_end = time.time() + min(timeout_s, 30.0)
+            t_end = time.time() + timeout_s   # (until the slowest rank's own time-out: a rank that arrives later has timed out anyway)
             while time.time() < t_end:
                 try:
                     os.utime(path, None)
