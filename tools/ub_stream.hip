@@ -34,7 +34,68 @@ __global__ __launch_bounds__(64) void k_shape(const uint8_t *img, double *planes
             if (NT) __builtin_nontemporal_store(v, o); else *o = v;
         }
 }
+// k_idct's traffic shape: a wave reads the 8 rows x 64 columns of three float64 planes (one 8-byte load per lane,
+// row and plane; non-temporal or plain) and writes the strip's 8 x 192 bytes of pixels (24 bytes per lane), and
+// computes nothing.  WAVES strips per workgroup.
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+template <bool NT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_shape_dec(const double *planes, uint8_t *img, int H, int W, int n) {
+    const int groups_x = W / 64, per_frame = groups_x * (H / 8);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = min((int)blockIdx.x * WAVES + wave, per_frame - 1), f = blockIdx.y;
+    const int ty = s / groups_x, gx = s - ty * groups_x;
+    const size_t F = (size_t)H * W * 3, plane = (size_t)H * W;
+    const double *in = planes + (size_t)f * 3 * plane;
+    double X[3][8];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double *p = in + ch * plane + (size_t)(ty * 8 + k) * W + gx * 64 + lane;
+            X[ch][k] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+    const int t = lane >> 3, j = lane & 7;
+    uint8_t *o = img + f * F + (size_t)(ty * 8 + j) * W * 3 + 3 * (gx * 64 + t * 8);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        u2 v;
+        v.x = (uint32_t)(long long)(X[q][0] + X[q][1] + X[q][2] + X[q][3]);
+        v.y = (uint32_t)(long long)(X[q][4] + X[q][5] + X[q][6] + X[q][7]);
+        __builtin_nontemporal_store(v, (u2 *)(o + 8 * q));
+    }
+}
+template <bool NT, int WAVES>
+static float run_dec(const double *pl[3], uint8_t *img, int H, int W, int n) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9f;
+    const unsigned per_frame = (unsigned)((W / 64) * (H / 8));
+    for (int it = 0; it < 12; it++) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k_shape_dec<NT, WAVES>), dim3((per_frame + WAVES - 1) / WAVES, n), dim3(64 * WAVES), 0, 0, pl[it % 3], img, H, W, n);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (it > 2 && ms < best) best = ms;
+    }
+    return best;
+}
+
 int main() {
+    {
+        const int H = 1080, W = 1920, n = 29;
+        const size_t F = (size_t)H * W * 3;
+        double *p0, *p1, *p2; uint8_t *img;
+        hipMalloc(&p0, F * n * 8); hipMalloc(&p1, F * n * 8); hipMalloc(&p2, F * n * 8); hipMalloc(&img, F * n + 64);
+        hipMemset(p0, 0, F * n * 8); hipMemset(p1, 0, F * n * 8); hipMemset(p2, 0, F * n * 8);
+        const double *pl[3] = {p0, p1, p2};
+        const double bytes = (double)F * n * 9;
+        float ms;
+        ms = run_dec<true, 1>(pl, img, H, W, n); printf("decode shape, non-temporal loads, 1 strip per workgroup:  %.3f ms  %.0f GB/s\n", ms, bytes / ms / 1e6);
+        ms = run_dec<true, 4>(pl, img, H, W, n); printf("decode shape, non-temporal loads, 4 strips per workgroup: %.3f ms  %.0f GB/s\n", ms, bytes / ms / 1e6);
+        ms = run_dec<true, 8>(pl, img, H, W, n); printf("decode shape, non-temporal loads, 8 strips per workgroup: %.3f ms  %.0f GB/s\n", ms, bytes / ms / 1e6);
+        ms = run_dec<false, 4>(pl, img, H, W, n); printf("decode shape, plain loads, 4 strips per workgroup:        %.3f ms  %.0f GB/s\n", ms, bytes / ms / 1e6);
+        hipFree(p0); hipFree(p1); hipFree(p2); hipFree(img);
+    }
+
     const int H = 1080, W = 1920, n = 29;
     const size_t F = (size_t)H * W * 3;
     uint8_t *img, *img2, *img3; double *planes, *planes2;
