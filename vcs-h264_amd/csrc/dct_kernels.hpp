@@ -368,20 +368,11 @@ __global__ __launch_bounds__(64 * kIdctWaves) IDCT_WPE void k_idct(
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *const s_t = s_tw[wave];
     const int t = lane >> 3, j = lane & 7;
+    for (int e = threadIdx.x; e < 192; e += 64 * kIdctWaves) s_q[(e >> 3) * kOutPad + (e & 7)] = DQ[64 + e];
     TailUnit tu;
-    const bool has_unit = tail_unit(g, n_frames, map, tu, kIdctWaves, wave);   // false: a valid unit, nothing stored
-    // The quantiser table is staged by the workgroup's first wave alone, in front of its own loads; the other
-    // waves request their planes at once and meet it at a barrier that is LDS traffic only (below).  Round 3
-    // staged it with all waves and a __syncthreads() in front of the first plane load: every workgroup began
-    // with a round trip to L2 for 1.5 KB and nothing else in flight.
-    // (Requested here, parked in LDS behind the plane loads' issue: loads return in order, so waiting for
-    // these three does not wait for the planes requested after them.)
-    const bool stager = wave == 0 || kIdctWaves == 1;
-    double qv[3] = {0.0, 0.0, 0.0};
-    if (stager) {
-#pragma unroll
-        for (int it = 0; it < 3; it++) qv[it] = DQ[64 + lane + 64 * it];
-    }
+    const bool has_unit = tail_unit(g, n_frames, map, tu, kIdctWaves, wave);
+    if (kIdctWaves > 1) __syncthreads();
+    if (!has_unit) return;
     const int ty = __builtin_amdgcn_readfirstlane(tu.ty), gx = __builtin_amdgcn_readfirstlane(tu.gx),
               f = __builtin_amdgcn_readfirstlane(tu.f);
     const int x = gx * 64 + lane;
@@ -431,15 +422,6 @@ __global__ __launch_bounds__(64 * kIdctWaves) IDCT_WPE void k_idct(
     for (int jj = 0; jj < 8; jj++)
         pp[jj] = MODE != 1 ? 0u : ONEBLK ? pred_px_m(ref, g, y, xo + jj, m8) : pred_px(ref, mv, g, y, xo + jj);
     __builtin_amdgcn_sched_barrier(0);
-    if (stager) {
-#pragma unroll
-        for (int it = 0; it < 3; it++) {
-            const int e = lane + 64 * it;
-            s_q[(e >> 3) * kOutPad + (e & 7)] = qv[it];
-        }
-    }
-    // s_q complete (every wave arrives exactly once): LDS only -- __syncthreads' fence would wait for the loads too
-    if (kIdctWaves > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     wave_lds_fence();
 
     int ycc[3][8];  // row i = j of the tile, 8 pixels, after stage 2
@@ -485,7 +467,7 @@ __global__ __launch_bounds__(64 * kIdctWaves) IDCT_WPE void k_idct(
     // tiles past the right edge (W not a multiple of 64): an offset beyond the frame, dropped by the
     // buffer's range check -- no branch (see above)
     const __amdgpu_buffer_rsrc_t r_out = buf_rsrc(outs + (size_t)f * out_stride, (uint32_t)(g.H * g.pitch));
-    const uint32_t oo = has_unit && gx * 64 + t * 8 < g.W ? (uint32_t)(y * g.pitch + 3 * xo) : 0xFFFFFF00u;
+    const uint32_t oo = gx * 64 + t * 8 < g.W ? (uint32_t)(y * g.pitch + 3 * xo) : 0xFFFFFF00u;
 #pragma unroll
     for (int q = 0; q < 3; q++) {
         u32x2 v;
