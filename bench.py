@@ -720,6 +720,17 @@ def main():
     dt, t_enq, _, _ = timed(sets, args.steps, warm + cond_steps)
     dt_ev, _, per, cyc = timed(sets, args.steps, 2, events=True)   # the GPU is warm: straight on
     ms, launches = per[0]
+    clock_ghz_events_pass = state.get("clock_ghz")      # (later passes overwrite state)
+    # the search kernel WITHOUT the Infinity Cache prefetch workgroups at its end (they stream the frames for
+    # the tail while the launch's last search workgroups drain): the part of the launch the vector-issue
+    # roof applies to.  One more short pass, prefetch off (the tail of that pass is slow: not reported).
+    me_alone_ms = None
+    if group is None and not args.no_extras:
+        ctx.set_l3_prefetch(0)
+        _, _, per_np, _ = timed(sets, max(4, args.steps // 2), 2, events=True)
+        ctx.set_l3_prefetch(-1)
+        me_alone_ms = per_np[0][0][vcs_hip.T_ME] / max(1, int(per_np[0][1][vcs_hip.T_ME]))
+        timed(sets, 2, 1)      # back to the headline's state (frames of the last GOP searched as the headline left them)
 
     # what was just timed: vectors of the last GOP (all shards'), static counts
     if group is not None:
@@ -852,17 +863,29 @@ def main():
                 valu_per_mb = round(kj["valu_wave_insts_per_dispatch"] / (tj["workload"]["frames_per_launch"] * N), 1)
             except Exception:
                 pass
-            clock_ghz = state.get("clock_ghz") or None
+            clock_ghz = clock_ghz_events_pass or None
             core = (8 + 4.5) * 27                # 8 + 4.5 wave passes of 27 instructions per macroblock
+            alone = me_alone_ms or me_ms
+
+            def frac(cycles_per_inst, t_ms):
+                return (round(valu_per_mb * cycles_per_inst * n0 * N / (1024 * clock_ghz * 1e9 * t_ms * 1e-3), 3)
+                        if clock_ghz else None)
             out["k_me16b_valu_issue"] = {
                 "clock_ghz_measured": round(clock_ghz, 3) if clock_ghz else None,
                 "valu_wave_insts_per_macroblock": valu_per_mb,
+                "valu_count_from": "profiles/hbm_traffic.json (PMC, this build)" if tj else "default (no PMC file for this build)",
                 "of_which_comparison_core": core,
-                "issue_cycles_per_macroblock": round(valu_per_mb * ISSUE_CYCLES_VOP3, 1),
-                "frac": (round(valu_per_mb * ISSUE_CYCLES_VOP3 * n0 * N / (1024 * clock_ghz * 1e9 * me_ms * 1e-3), 3)
-                         if clock_ghz else None),
-                "how": "vector wave-instructions per macroblock (PMC count in profiles/) x 4 issue cycles "
-                       "(VOP3, tools/ub_bits.hip) over 1,024 SIMDs x measured clock x launch time"}
+                "launch_ms": round(me_ms, 4),
+                "search_alone_ms": round(alone, 4) if me_alone_ms else None,
+                # one vector wave-instruction occupies a SIMD for 4 cycles (SQ_ACTIVE_INST_VALU counts exactly
+                # one quad-cycle per instruction in profiles/); tools/ub_bits.hip measures 3.65 for the
+                # v_bitop3 / v_bcnt mix when nothing else competes
+                "frac": frac(4.0, alone),
+                "frac_at_3_65_cycles": frac(3.65, alone),
+                "frac_of_whole_launch": frac(4.0, me_ms),
+                "how": "vector wave-instructions per macroblock x 4 issue cycles over 1,024 SIMDs x measured clock x "
+                       "the search's time without the prefetch workgroups at the launch's end (search_alone_ms: a "
+                       "pass with vcs_set_l3_prefetch(0)); frac_of_whole_launch prices the launch as timed in the step"}
         if me_name == "k_me16g":
             # The motion search is bound by vector-ALU issue, not by HBM: how close it is to THAT
             # roof, priced with the clock the chip held in this run (longest workgroup lifetime in

@@ -287,6 +287,14 @@ int vcs_gop_get_mv(vcs_ctx *ctx, int first_slot, int n, int16_t *mv_out,
 int vcs_gop_get_planes(vcs_ctx *ctx, int slot, void *planes_out);
 int vcs_gop_get_decoded(vcs_ctx *ctx, int slot, uint8_t *bgr_out);
 int vcs_sync(vcs_ctx *ctx);
+/* How vcs_gop_encode brings the batch's frames into the Infinity Cache for the
+ * encoder tail (the search kernels read them as scattered pieces that do not
+ * stay there): 1 = by the last workgroups of the search launch (default),
+ * 2 = a separate pass between search and tail, 0 = not at all, -1 = back to
+ * the default / VCS_L3_PREFETCH.  Scheduling only -- results never change;
+ * bench.py uses 0 to time the search kernel without its prefetch workgroups.
+ * (No reference counterpart: encoder.py:58-66 runs on the CPU.)               */
+int vcs_set_l3_prefetch(vcs_ctx *ctx, int mode);
 
 /* Device-side plumbing for the multi-GPU host layer (RCCL broadcast of the I
  * frame, gather of motion vectors): raw HBM pointers of the context's

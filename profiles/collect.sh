@@ -7,12 +7,14 @@
 #      pass, the TCC block holds four counters; never combined with sys/hip/hsa tracing)
 # Afterwards, here: cp gpurun_out/profiles_<tag>/{pmc_per_dispatch.json,kernel_stats.csv} profiles/<tag>/
 # and python profiles/make_traffic.py profiles/<tag>/pmc_per_dispatch.json -> profiles/hbm_traffic.json
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="$root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
+# --with-decode: k_idct over the same GOP sets behind the timed loop (its kernel-trace average and its
+# FETCH_SIZE / WRITE_SIZE land in the same files)
+B="$root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --with-decode"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $B > $out/stats.log 2>&1
 cp $out/stats/*/*_kernel_stats.csv $out/kernel_stats.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" \

@@ -20,9 +20,11 @@ ALG = {  # algorithmic bytes per launch (29 P frames)
     "k_bits_ref": F + TABLE,                      # one reference frame in, the chunk table out
     "k_fdct<residual>": FRAMES * (10 * F + 4 * N),
     "k_me16_sums": F + N * 128 * 4,
+    "k_idct<residual>": FRAMES * (8 * F + F + 4 * N + F),   # planes + reference + vectors in, the frame out
 }
 PMC_PREFIX = {"vcs::k_me16b": "k_me16b", "vcs::k_bits_cur": "k_bits_cur", "vcs::k_bits_ref": "k_bits_ref",
-              "vcs::k_fdct<1, 0,": "k_fdct<residual>", "vcs::k_me16_sums": "k_me16_sums"}   # kernel-name prefixes in the PMC summary
+              "vcs::k_fdct<1, 0,": "k_fdct<residual>", "vcs::k_me16_sums": "k_me16_sums",
+              "vcs::k_idct<1, 0,": "k_idct<residual>"}   # kernel-name prefixes in the PMC summary
 
 
 def main(path):
@@ -31,8 +33,8 @@ def main(path):
     kernels = {}
     for prefix, name in PMC_PREFIX.items():
         keys = [k for k in pmc if k.startswith(prefix) and "primer" not in k]
-        if not keys and name == "k_me16_sums":   # folded into k_bits_ref + k_bits_cur since round 3: absent from batch runs
-            continue
+        if not keys and name in ("k_me16_sums", "k_idct<residual>"):   # folded into k_bits_ref + k_bits_cur since round 3: absent
+            continue                                                     # from batch runs; k_idct only with --with-decode
         if len(keys) != 1:
             sys.exit("expected one kernel starting with %r, found %r" % (prefix, keys))
         v = pmc[keys[0]]

@@ -85,6 +85,7 @@ struct vcs_ctx {
         bool pending = false;               // ev_done has to be waited for before the table is read
         hipEvent_t ev_done = nullptr;
     } tabs[2];
+    int l3_mode = -1;               // vcs_set_l3_prefetch: -1 = the environment's choice (default: inside the search launch)
     bool next_ready = false;        // the alternate reference buffer holds the next GOP's I frame
     hipEvent_t ev_next = nullptr;   // ... as of this event (recorded on the stream that wrote it)
     hipStream_t s_side = nullptr;
@@ -1401,7 +1402,9 @@ int vcs_gop_encode(vcs_ctx *c, int first, int n) {
     // sub-batches that do (search, prefetch, tail per sub-batch; 8 frames at 4K) -- otherwise what
     // is read first would be gone again when the tail gets there.
     size_t chunk = (size_t)n;
-    const bool pf = l3_prefetch_on() && n >= 2 && N > 0;
+    const bool l3_on = c->l3_mode < 0 ? l3_prefetch_on() : c->l3_mode != 0;
+    const bool l3_in_search = c->l3_mode < 0 ? l3_prefetch_in_search() : c->l3_mode == 1;
+    const bool pf = l3_on && n >= 2 && N > 0;
     if (pf && (size_t)n * c->Fs > l3_prefetch_max_bytes()) {
         chunk = l3_prefetch_max_bytes() / c->Fs;
         if (chunk >= 4) chunk &= ~(size_t)3;          // whole 4-frame groups of the search kernel
@@ -1425,7 +1428,7 @@ int vcs_gop_encode(vcs_ctx *c, int first, int n) {
         const uint8_t *cc = curs + f0 * c->Fs;
         int16_t *mvc = mv + f0 * N * 2;
         c->t_no_count = f0 > 0;                      // timing: one "launch" per call, whatever the batching
-        c->pf_in_search = !whole_me && pf_on && m >= 2 && l3_prefetch_in_search();
+        c->pf_in_search = !whole_me && pf_on && m >= 2 && l3_in_search;
         rc = whole_me ? VCS_OK : launch_me(c, c->d_ref, cc, c->Fs, m, mvc, c->g_ns + first + f0, nullptr);
         const bool pf_done = c->pf_in_search;
         c->pf_in_search = false;
@@ -1492,6 +1495,14 @@ int vcs_gop_get_decoded(vcs_ctx *c, int slot, uint8_t *bgr_out) {
     if (!c->gop_dec) return fail(c, VCS_E_STATE, "GOP slots were reserved without decode buffers");
     HIP_TRY(c, hipMemcpyAsync(bgr_out, c->g_dec + (size_t)slot * c->Fs, c->F, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_set_l3_prefetch(vcs_ctx *c, int mode) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (mode < -1 || mode > 2) return fail(c, VCS_E_ARG, "l3 prefetch mode %d (want -1, 0, 1 or 2)", mode);
+    c->l3_mode = mode;
     return VCS_OK;
 }
 

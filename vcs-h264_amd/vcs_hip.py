@@ -102,6 +102,7 @@ SIGNATURES = {
     "vcs_stream_signal": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_handle": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_void_p)]),
     "vcs_ref_swap": (ctypes.c_int, [_c_ctx]),
+    "vcs_set_l3_prefetch": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
     "vcs_ref_next_ready": (ctypes.c_int, [_c_ctx, ctypes.c_void_p]),
     "vcs_set_ref_next": (ctypes.c_int, [_c_ctx, ctypes.c_void_p]),
     "vcs_timing_enable": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
@@ -570,6 +571,10 @@ class Context:
     def ref_swap(self):
         """Exchange the current and the alternate reference buffer (dev_ptr 0 <-> 3)."""
         self._ck(self._lib.vcs_ref_swap(self._h))
+
+    def set_l3_prefetch(self, mode):
+        """-1 default, 0 off, 1 inside the search launch, 2 separate pass (vcs_set_l3_prefetch)."""
+        self._ck(self._lib.vcs_set_l3_prefetch(self._h, int(mode)))
 
     def ref_next_ready(self, written_on_stream=0):
         """The alternate reference buffer (dev_ptr 3) holds the next GOP's I frame: its search tables are cut
