@@ -472,6 +472,13 @@ __device__ __forceinline__ BitsTask bits_task(int j, int lane, int n2, uint32_t 
     return k;
 }
 
+#ifdef VCS_EXP_PHASES   // experiment builds only (tools/gpu_phases_bits.py): where a search wave's time goes
+__device__ unsigned long long g_me16b_phases[8];   // [0..4]: shader cycles in prologue / first pass / between / second pass / end; [5]: waves sampled
+#define BITS_PROBE(i) do { if (probing) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] = t_; } } while (0)
+#else
+#define BITS_PROBE(i) do { } while (0)
+#endif
+
 template <int NF>
 __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value) {
     constexpr int STEP = 5;
@@ -539,6 +546,11 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
     const int xcd = blockIdx.x & 7;
     int ul = oct * kBitsWpw + wave;
     BitsUnit u;
+#ifdef VCS_EXP_PHASES
+    const bool probing = ((blockIdx.x >> 3) & 15) == 3;   // one workgroup octet in 16
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    BITS_PROBE(0);
     if (bits_unit(ul, A, xcd, u)) {
         // A wave's first loads -- the static-test records, the first chunk, the planes of the first two
         // row pairs -- are all requested before the first of them is waited for: one round trip at the
@@ -598,6 +610,7 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
         splanes_wait(pa);
         if (!searching)   // nothing may be in flight when the wave ends (the LDS-direct loads write LDS)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BITS_PROBE(1);
         if (searching) {
             // ---- first pass: planes of the block in SGPRs ----------------------------------------
             uint32_t acc[NF];
@@ -656,6 +669,7 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
 #pragma unroll
             for (int f = 0; f < NF; f++) best[f] = base + (acc[f] << 15);
         }
+        BITS_PROBE(2);
         // everything is loaded and derived again from here on (see BitsArgs)
         asm volatile("" : "+s"(ul));
         const BitsArgsP B = bits_args_again();
@@ -676,6 +690,7 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
             // the LDS-direct loads have landed (this wave's own: its vmcnt is what orders them)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wave_lds_fence();
+            BITS_PROBE(3);
             // (Requesting EVERY pass's chunk a pass ahead -- the first pass's two chunk buffers in turn -- needs
             // 93 registers with the 24 of the planes: five waves per SIMD instead of six, or scratch traffic
             // in the frame loop when capped at 80.  Only pass 0's is ahead.)
@@ -707,6 +722,7 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
                 }
             }
             wave_lds_fence();
+            BITS_PROBE(4);
             if (lane < n2) {
                 const uint32_t base2 = (B->sums[(size_t)u.blk * kMe16SumStride + 64 + lane] << 7) | (uint32_t)(64 + lane);
 #pragma unroll
@@ -762,6 +778,18 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
             }
         }
     }
+#ifdef VCS_EXP_PHASES
+    if (probing && lane == 0 && ph[1] && ph[2]) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (!ph[3]) ph[3] = ph[4] = ph[2];
+        atomicAdd(&g_me16b_phases[0], ph[1] - ph[0]);
+        atomicAdd(&g_me16b_phases[1], ph[2] - ph[1]);
+        atomicAdd(&g_me16b_phases[2], ph[3] - ph[2]);
+        atomicAdd(&g_me16b_phases[3], ph[4] - ph[3]);
+        atomicAdd(&g_me16b_phases[4], t_end - ph[4]);
+        atomicAdd(&g_me16b_phases[5], 1ull);
+    }
+#endif
     // (one workgroup in 64 reports: 8,040 workgroups adding to the same two words serialise in L2 --
     // ~12 ns per atomic -- and a wave keeps its slot until its atomics are done: with every workgroup
     // reporting, the instrumented launch could not end before 8,040 x 25 ns = 0.2 ms)

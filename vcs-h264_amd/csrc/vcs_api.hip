@@ -1802,6 +1802,15 @@ extern "C" int vcs_me_phases(vcs_ctx *c, uint64_t *out9) {
 #endif
 
 #ifdef VCS_EXP_PHASES
+extern "C" int vcs_me16b_phases(vcs_ctx *c, uint64_t *out8) {
+    int rc = use(c);
+    if (rc) return rc;
+    static unsigned long long zero[8] = {0};
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(vcs::g_me16b_phases), 64));
+    HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(vcs::g_me16b_phases), zero, 64));
+    return VCS_OK;
+}
 extern "C" int vcs_me_wg_times(vcs_ctx *c, uint64_t *out, int n) {
     int rc = use(c);
     if (rc) return rc;
