@@ -387,29 +387,60 @@ constexpr int kBitsWpw = VCS_BITS_WPW;   // waves (units) per k_me16b workgroup:
 // kept -- kept, hipcc spilled ~50 scalars to vector lanes around the loops (v_writelane / v_readlane
 // are vector instructions, in a kernel bound by vector issue; scalar loads and scalar arithmetic are
 // not).  Round 3's build: 156 lane moves per wave.
+#define BITS_ARGS_FIELDS(P32, PPTR)                                                                                   \
+    PPTR(rtab, const uint32_t *) PPTR(cpl, const uint32_t *) PPTR(binfo, const uint2 *) PPTR(sums, const uint32_t *)     \
+    PPTR(mv, int16_t *) PPTR(cost_out, unsigned long long *) PPTR(clk_out, unsigned long long *)                        \
+    PPTR(pf_base, const uint8_t *) PPTR(ns_part, const uint32_t *) PPTR(n_static, uint32_t *)                           \
+    P32(H, int) P32(W, int) P32(N, int) P32(nbx, int) P32(nby, int) P32(thresh, uint32_t) P32(never_static, int)        \
+    P32(n_frames, int) P32(ngroups, int) P32(pf_total16, uint32_t) P32(n_search_wgs, int) P32(pf_octets, int)           \
+    P32(pf_ratio, int) P32(ns_per_frame, int) P32(a0, int) P32(na, int) P32(per_col_magic, uint32_t)                    \
+    P32(ngroups_magic, uint32_t)
 struct BitsArgs {
-    const uint32_t *rtab, *cpl;
-    const uint2 *binfo;
-    const uint32_t *sums;
-    int16_t *mv;
-    unsigned long long *cost_out, *clk_out;
-    const uint8_t *pf_base;
-    const uint32_t *ns_part;
-    uint32_t *n_static;
-    int H, W, N, nbx, nby;
-    uint32_t thresh;
-    int never_static, n_frames, ngroups;
-    uint32_t pf_total16;
-    int n_search_wgs, pf_octets, pf_ratio, ns_per_frame, a0, na;
-    uint32_t per_col_magic, ngroups_magic;   // magic_u32 of nby * ngroups and of ngroups: the unit decode is scalar,
-                                             // and a scalar division by a runtime value is a 25-instruction vector sequence
+#define BITS_DECL32(f, T) T f;
+#define BITS_DECLP(f, T) T f;
+    BITS_ARGS_FIELDS(BITS_DECL32, BITS_DECLP)
+#undef BITS_DECL32
+#undef BITS_DECLP
+    // (per_col_magic, ngroups_magic: magic_u32 of nby * ngroups and of ngroups -- the unit decode is scalar, and a
+    // scalar division by a runtime value is a 25-instruction vector sequence)
+    uint32_t pad_[6];   // 176 bytes = 16 + 16 + 8 + 4 dwords: what bits_args_fetch loads
 };
+static_assert(sizeof(BitsArgs) == 176, "bits_args_fetch loads 44 dwords");
 typedef const __attribute__((address_space(4))) BitsArgs *BitsArgsP;
 __device__ __forceinline__ BitsArgsP bits_args() { return (BitsArgsP)__builtin_amdgcn_kernarg_segment_ptr(); }
 __device__ __forceinline__ BitsArgsP bits_args_again() {   // the same pointer, but nothing loaded through the old one is reused
     BitsArgsP p = bits_args();
     asm volatile("" : "+s"(p));
     return p;
+}
+// All of the arguments in ONE batch of scalar loads and one wait.  Read field by field where they are used, hipcc
+// places a scalar load and a wait of its own at every first use: twelve round trips to the scalar cache in a row
+// at the start of every wave, before the first request for data could leave (2-3 k cycles of the ~5.7 k a wave
+// spends before its first comparison).
+typedef uint32_t u32x16a_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8a_t __attribute__((ext_vector_type(8)));
+struct BitsWords { u32x16a_t a, b; u32x8a_t c; u32x4_t d; };
+template <int OFF>
+__device__ __forceinline__ uint32_t bits_word(const BitsWords &w) {
+    static_assert(OFF % 4 == 0 && OFF >= 0 && OFF < 176, "inside the 44 dwords");
+    if constexpr (OFF < 64) return w.a[OFF / 4];
+    else if constexpr (OFF < 128) return w.b[(OFF - 64) / 4];
+    else if constexpr (OFF < 160) return w.c[(OFF - 128) / 4];
+    else return w.d[(OFF - 160) / 4];
+}
+__device__ __forceinline__ BitsArgs bits_args_fetch(BitsArgsP p) {
+    BitsWords w;
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx8 %2, %4, 0x80\n\t"
+                 "s_load_dwordx4 %3, %4, 0xa0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(w.a), "=&s"(w.b), "=&s"(w.c), "=&s"(w.d) : "s"(p));
+    BitsArgs a;
+#define BITS_GET32(f, T) a.f = (T)bits_word<offsetof(BitsArgs, f)>(w);
+#define BITS_GETP(f, T)                                                                                    \
+    a.f = (T)(((unsigned long long)bits_word<offsetof(BitsArgs, f) + 4>(w) << 32) | bits_word<offsetof(BitsArgs, f)>(w));
+    BITS_ARGS_FIELDS(BITS_GET32, BITS_GETP)
+#undef BITS_GET32
+#undef BITS_GETP
+    return a;
 }
 // 65536 / n + 1 (x / n for x < 512, n <= 36, as a multiply and a shift): looked up, not divided
 __device__ __constant__ const uint32_t kBitsInv[40] = {
@@ -421,28 +452,28 @@ struct BitsUnit {
     int bl, blk, f0, nf, x, y, i_min, j_min, nci, ncj, ncand;
     uint32_t inv_ncj;
 };
-__device__ __forceinline__ bool bits_unit(int ul, BitsArgsP A, int xcd, BitsUnit &u) {
+__device__ __forceinline__ bool bits_unit(int ul, const BitsArgs &A, int xcd, BitsUnit &u) {
     constexpr int BS = 16, WIN = 32, STEP = 5;
-    const int ngroups = A->ngroups, na = A->na;
-    const uint32_t ngroups_magic = A->ngroups_magic;
-    const int per_col = A->nby * ngroups;
+    const int ngroups = A.ngroups, na = A.na;
+    const uint32_t ngroups_magic = A.ngroups_magic;
+    const int per_col = A.nby * ngroups;
     const int chunk = (((na + 7) / 8) * per_col + kBitsWpw - 1) / kBitsWpw * kBitsWpw;   // units per XCD (the XCDs with one column less idle at the end)
-    const int lc = (int)div_magic((uint32_t)ul, A->per_col_magic);
+    const int lc = (int)div_magic((uint32_t)ul, A.per_col_magic);
     u.bl = lc * 8 + xcd;   // column inside the band
     if (!(ul < chunk && u.bl < na)) return false;
     const int rem = ul - lc * per_col;
-    const int byi = (int)div_magic((uint32_t)rem, ngroups_magic), bxi = A->a0 + u.bl;
+    const int byi = (int)div_magic((uint32_t)rem, ngroups_magic), bxi = A.a0 + u.bl;
     // the groups of a position differ in size (29 frames: 8, 7, 7, 7): rotated from position to
     // position, so that the same wave slot (SIMD) does not get the large one every time (-0.4 % of
     // the step in 3 of 3 A/B pairs)
     const int gr = rem - byi * ngroups + byi;
     const int grp = gr - ngroups * (int)div_magic((uint32_t)gr, ngroups_magic);
-    u.blk = byi * A->nbx + bxi;
-    bits_group(A->n_frames, ngroups, ngroups_magic, grp, u.f0, u.nf);
+    u.blk = byi * A.nbx + bxi;
+    bits_group(A.n_frames, ngroups, ngroups_magic, grp, u.f0, u.nf);
     u.x = bxi * BS; u.y = byi * BS;
     u.i_min = max(u.y - WIN, 0);
     u.j_min = max(u.x - WIN, 0);
-    const int i_max = min(u.y + WIN, A->H), j_max = min(u.x + WIN, A->W);
+    const int i_max = min(u.y + WIN, A.H), j_max = min(u.x + WIN, A.W);
     const int ri = i_max - BS - u.i_min, rj = j_max - BS - u.j_min;
     u.nci = ri >= 1 ? (ri - 1) / STEP + 1 : 0;
     u.ncj = rj >= 1 ? (rj - 1) / STEP + 1 : 0;
@@ -485,7 +516,8 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
     static_assert(NF % 4 == 0 && NF <= 8, "two plane buffers in turn; the split pass pairs frame f with f + NF / 2 in one counter word; NF * 6 lanes prefetch");
     using L = BitsLds<NF>;
     __shared__ __attribute__((aligned(16))) uint8_t s_lds[kBitsWpw * L::kWave];
-    const BitsArgsP A = bits_args();
+    const BitsArgs A_ = bits_args_fetch(bits_args());
+    const BitsArgs *const A = &A_;
     // clk_out (timing on): shader-clock cycles and 100 MHz ticks this workgroup lived, summed over
     // the workgroups: their quotient is the clock the chip held under this load
     const bool clocked = A->clk_out != nullptr && threadIdx.x == 0 && (blockIdx.x & 63u) == 0;
@@ -551,7 +583,7 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
 #endif
     BITS_PROBE(0);
-    if (bits_unit(ul, A, xcd, u)) {
+    if (bits_unit(ul, A_, xcd, u)) {
         // A wave's first loads -- the static-test records, the first chunk, the planes of the first two
         // row pairs -- are all requested before the first of them is waited for: one round trip at the
         // start of a wave instead of ten in a row (round 3 read the eight records by scalar loads, each
@@ -672,8 +704,9 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
         BITS_PROBE(2);
         // everything is loaded and derived again from here on (see BitsArgs)
         asm volatile("" : "+s"(ul));
-        const BitsArgsP B = bits_args_again();
-        bits_unit(ul, B, xcd, u);
+        const BitsArgs B_ = bits_args_fetch(bits_args_again());
+        const BitsArgs *const B = &B_;
+        bits_unit(ul, B_, xcd, u);
         if (searching && u.ncand > 64) {
             // ---- second pass: candidates 64.., lane = (candidate, row pair), planes from LDS ------
             // n2 candidates x 8 row pairs = up to 288 tasks = 4.5 wave passes.  The half-filled last
