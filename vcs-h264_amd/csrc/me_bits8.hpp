@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void k_me8b(const uint32_t *__restrict__ rtab,
                                               int ns_per_frame, uint32_t *__restrict__ n_static,
                                               uint32_t per_col_magic, uint32_t ngroups_magic) {
     constexpr int BS = 8, WIN = 16, STEP = 3;
-    __shared__ __attribute__((aligned(16))) uint8_t s_dump[4 * 1024];   // where prefetched bytes go: nobody reads it
+    // per wave: 1 KB where prefetched bytes go (nobody reads them), reused by the arg-min ([frame][64 keys])
+    static_assert(NF <= 16 && 64 % NF == 0, "the arg-min gives frame f the lanes f * (64 / NF) ..");
+    __shared__ __attribute__((aligned(16))) uint8_t s_dump[4 * NF * 256];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Infinity Cache prefetch for the tail kernel: the workgroups behind the search's own stream the
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void k_me8b(const uint32_t *__restrict__ rtab,
         for (uint32_t i = w * 64u; i < pf_total16; i += nw * 64u, it++) {   // uniform trip count
             if (i + (uint32_t)lane < pf_total16)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    r_pf, (__attribute__((address_space(3))) void *)(s_dump + wave * 1024), 16,
+                    r_pf, (__attribute__((address_space(3))) void *)(s_dump + wave * (NF * 256)), 16,
                     (int)((i + (uint32_t)lane) << 4), 0, 0, 0);
             if ((it & 7u) == 7u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -241,15 +243,13 @@ __global__ __launch_bounds__(256) void k_me8b(const uint32_t *__restrict__ rtab,
     const int ncand = nci * ncj;
     const uint32_t inv_ncj = ncj ? 65536u / (uint32_t)ncj + 1u : 0u;   // cand / ncj for cand < 64, ncj <= 8
 
-    uint32_t skip = 0;   // bit f: nothing to search for frame f0 + f
-#pragma unroll
-    for (int f = 0; f < NF; f++) {
-        if (f < nf) {
-            const uint32_t sd = binfo[(size_t)(f0 + f) * g.N + blk].x;
-            if (!g.never_static && sd <= g.thresh) skip |= 1u << f;
-        } else {
-            skip |= 1u << f;
-        }
+    // per frame: static?  Lane f reads frame f's record: one round trip (NF scalar loads, each behind a branch,
+    // were NF in a row at the start of every wave; k_me16b: -5.7 % from the same change)
+    uint32_t skip;   // bit f: nothing to search for frame f0 + f
+    {
+        const uint32_t sd = binfo[(size_t)(f0 + max(min(lane, nf - 1), 0)) * g.N + blk].x;
+        const bool st = lane >= nf || (!g.never_static && sd <= g.thresh);
+        skip = (uint32_t)__ballot(st) & (NF >= 32 ? 0xFFFFFFFFu : (1u << NF) - 1u);
     }
     const uint32_t all = NF >= 32 ? 0xFFFFFFFFu : (1u << NF) - 1u;
     uint32_t acc[NF];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_me8b(const uint32_t *__restrict__ rtab,
                 const int e = lane + 64 * i, fr = min(e / 12, nf - 1), piece = e - (e / 12) * 12;
                 if (e < NF * 12)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        r_c, (__attribute__((address_space(3))) void *)(s_dump + wave * 1024), 16,
+                        r_c, (__attribute__((address_space(3))) void *)(s_dump + wave * (NF * 256)), 16,
                         (int)((uint32_t)fr * (uint32_t)(cfs * 4) + 16u * (uint32_t)piece), 0, 0, 0);
             }
         }
@@ -300,34 +300,50 @@ __global__ __launch_bounds__(256) void k_me8b(const uint32_t *__restrict__ rtab,
         }
     }
     // ---- arg-min per frame (motion.py:149: strict <, raster order = lowest index on ties) -------
-    const uint32_t sr = sums[(size_t)blk * kMe8SumStride + (act ? lane : 0)];
+    // key = (cost << 6) | candidate, cost = sum(r) - sum(c) + 256 * #{r < c} without the -sum(c), which is the
+    // same for all candidates; a lane without a candidate has compared candidate 0's chunks: candidate 0's cost
+    // with a higher index, which never wins.  Through LDS (k_me16b: why): the 64 keys of frame f go to row f,
+    // the 64 / NF lanes of frame f take 16 keys each, DPP finishes inside them.
+    const uint32_t base = (sums[(size_t)blk * kMe8SumStride + (act ? lane : 0)] << 6) | (uint32_t)lane;
+    constexpr int LPF = 64 / NF, KPL = 64 / LPF;   // lanes per frame, keys per lane
     uint32_t my_key = 0xFFFFFFFFu;
+    const bool searching = skip != all && ncand > 0;
+    if (searching) {
+        uint32_t *s_red = (uint32_t *)(s_dump + wave * (NF * 256));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-direct loads into this area have landed
+        wave_lds_fence();
 #pragma unroll
-    for (int f = 0; f < NF; f++) {
-        if (!((skip >> f) & 1u)) {   // scalar
-            const uint32_t key = wave_min_u32(act ? (((sr + 256u * acc[f]) << 6) | (uint32_t)lane) : 0xFFFFFFFFu);
-            if (lane == f) my_key = key;
+        for (int f = 0; f < NF; f++) s_red[f * 64 + lane] = base + (acc[f] << 14);
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < KPL / 4; q++) {
+            const uint4 v = *(const uint4 *)(s_red + lane * KPL + 4 * q);
+            my_key = min(my_key, min(min(v.x, v.y), min(v.z, v.w)));
         }
+        if (LPF >= 2) my_key = min(my_key, dpp_u32<0xB1>(my_key));    // quad_perm:[1,0,3,2]
+        if (LPF >= 4) my_key = min(my_key, dpp_u32<0x4E>(my_key));    // quad_perm:[2,3,0,1]
+        if (LPF >= 8) my_key = min(my_key, dpp_u32<0x141>(my_key));   // row_half_mirror
     }
-    if (lane < nf) {
-        const size_t o = (size_t)(f0 + lane) * g.N + blk;
-        const uint2 bi = binfo[o];
-        uint32_t mvw = 0u;
-        unsigned long long cw = bi.x;              // static block: [0, 0], cost = the difference
-        if (!((skip >> lane) & 1u)) {
-            int bx = 0, byy = 0;
-            cw = 9999999999ull;                    // motion.py:120: no candidate
-            if (my_key != 0xFFFFFFFFu) {
+    const int fr = lane / LPF;
+    if (lane % LPF == 0 && fr < nf) {
+        const size_t o = (size_t)(f0 + fr) * g.N + blk;
+        const bool searched = !((skip >> fr) & 1u), found = searched && searching;
+        uint32_t mvw = 0u;                         // static block: [0, 0]
+        if (searched) {
+            int bx = 0, byy = 0;                   // motion.py:120: no candidate
+            if (found) {
                 const int cb = (int)(my_key & 63u);
                 const int cbi = (int)(((uint32_t)cb * inv_ncj) >> 16);
                 byy = i_min + cbi * STEP;
                 bx = j_min + (cb - cbi * ncj) * STEP;
-                cw = (my_key >> 6) - bi.y;
             }
             mvw = (uint32_t)(uint16_t)(bx - x) | ((uint32_t)(uint16_t)(byy - y) << 16);  // [dx, dy]
         }
         *(uint32_t *)(mv + 2 * o) = mvw;
-        if (cost_out) cost_out[o] = cw;
+        if (cost_out) {   // a debugging output: only then is the record read again
+            const uint2 bi = binfo[o];
+            cost_out[o] = !searched ? (unsigned long long)bi.x : found ? (unsigned long long)((my_key >> 6) - bi.y) : 9999999999ull;
+        }
     }
 }
 
