@@ -344,6 +344,23 @@ int vcs_intra_chroma8x8(vcs_ctx *ctx, const uint8_t *Cr, const uint8_t *Cb, doub
  * of a float64 H x W residual plane (H, W multiples of 4).  No running upstream code
  * pins it; exact for integer-valued input.                                      */
 int vcs_intra_transform4x4(vcs_ctx *ctx, const double *res, double *out);
+/* The same four kernels over a BATCH of I frames resident in HBM (the I frames of
+ * many GOPs: intraframe.py processes one image per run, :321-350).  A single
+ * 1080p frame cannot fill the chip -- chroma8x8 is serial down each of its 240
+ * block columns because Cb is predicted from the residual above (:266) --, n
+ * frames give n times the independent columns.  reserve: device buffers for
+ * n_frames (planes must be multiples of 16); upload: Y / Cr / Cb as n x H x W
+ * uint8 each; run: `what` is a mask of 1 = luma4x4, 2 = luma16x16, 4 =
+ * chroma8x8, 8 = the 4x4 transform of the luma4x4 residual (needs 1), one launch
+ * per kernel over frames [first, first + n), asynchronous; get: one frame's
+ * results (`which`: 0 luma4x4 -> res, pred, modes; 1 luma16x16 -> the same;
+ * 2 chroma8x8 -> crres, crpred, cbres, cbpred, modes; 3 transform -> out),
+ * null pointers are skipped.  Results are identical to the single-frame calls. */
+int vcs_intra_batch_reserve(vcs_ctx *ctx, int n_frames);
+int vcs_intra_batch_upload(vcs_ctx *ctx, int first, int n, const uint8_t *Y, const uint8_t *Cr, const uint8_t *Cb);
+int vcs_intra_batch_run(vcs_ctx *ctx, int first, int n, int what);
+int vcs_intra_batch_get(vcs_ctx *ctx, int frame, int which, double *p0, double *p1, double *p2, double *p3,
+                        double *modes);
 
 /* 4:2:0 chroma subsampling (next row N4; reference ChromaSubsampling/chroma.py:8-21, a
  * run-at-import script upstream): BGR -> YCrCb, cv2.boxFilter(ksize=(2,2)) over Cr and Cb,

@@ -621,6 +621,43 @@ def test_intra_1080p_vs_oracle(vh, oracle):
         assert np.array_equal(coef[8:12, 20:24], np.round(np.matmul(np.matmul(C, blk), C.transpose())))
 
 
+def test_intra_batch_vs_oracle(vh, oracle):
+    """vcs_intra_batch_*: the intra kernels over several I frames in one launch each (blockIdx.y = frame) --
+    every frame's results against the oracle, a sub-range run, and the error paths."""
+    rng = np.random.default_rng(11)
+    H, W, n = 96, 160, 5
+    Y, Cr, Cb = [rng.integers(0, 256, (n, H, W)).astype(np.uint8) for _ in range(3)]
+    Y[2] = 77                                       # a flat frame: ties between the predictors
+    Cb[3, :, :] = (np.arange(W) % 256).astype(np.uint8)
+    with vh.Context(H, W, 16) as c:
+        with pytest.raises(vh.VcsError):
+            c.intra_batch_run(0, 1)                 # nothing reserved
+        c.intra_batch_reserve(n)
+        c.intra_batch_upload(0, Y, Cr, Cb)
+        c.intra_batch_run(0, n)                     # all four kernels over all frames
+        for f in range(n):
+            for which, want in ((0, oracle.intra_luma4x4(Y[f])), (1, oracle.intra_luma16x16(Y[f])),
+                                (2, oracle.intra_chroma8x8(Cr[f], Cb[f]))):
+                got = c.intra_batch_get(f, which)
+                assert len(got) == len(want)
+                for a, b in zip(got, want):
+                    assert np.array_equal(a, b), (f, which)
+            assert np.array_equal(c.intra_batch_get(f, 3), oracle.intra_transform4x4(oracle.intra_luma4x4(Y[f])[0])), f
+        # frames 3..4 replaced and re-run alone: the others keep their results
+        Y2 = rng.integers(0, 256, (2, H, W)).astype(np.uint8)
+        c.intra_batch_upload(3, Y2, Cr[3:], Cb[3:])
+        c.intra_batch_run(3, 2, vh.Context.INTRA_LUMA4)
+        assert np.array_equal(c.intra_batch_get(4, 0)[0], oracle.intra_luma4x4(Y2[1])[0])
+        assert np.array_equal(c.intra_batch_get(1, 0)[0], oracle.intra_luma4x4(Y[1])[0])
+        with pytest.raises(vh.VcsError):
+            c.intra_batch_run(4, 2)                 # past the reserved frames
+        with pytest.raises(vh.VcsError):
+            c.intra_batch_run(0, 1, 8)              # the transform needs the luma 4x4 residual of the same call
+    with vh.Context(72, 160, 8) as c:
+        with pytest.raises(vh.VcsError):
+            c.intra_batch_reserve(2)                # 72 is not a multiple of 16
+
+
 def test_intra_transform_dropin(vh):
     sys_path = __import__("sys").path
     idir = __import__("os").path.join(__import__("conftest").PKG, "IntraframeCompression")

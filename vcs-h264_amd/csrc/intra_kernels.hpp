@@ -32,10 +32,15 @@ __device__ __forceinline__ int cost16(const int (&p)[16], const int (&y)[16]) {
 // k_intra_luma4: one thread per 4x4 block (adjacent lanes = horizontally
 // adjacent blocks, so a wave's row stores are contiguous).
 // --------------------------------------------------------------------------
+// (all three prediction kernels: blockIdx.y = frame of a batch; in_stride / out_stride / modes_stride are
+// the distances between consecutive frames' planes in elements -- 0 for the single-frame entry points)
 __global__ __launch_bounds__(256) void k_intra_luma4(const uint8_t *__restrict__ Y, int H, int W,
                                                      double *__restrict__ res,
                                                      double *__restrict__ pred,
-                                                     double *__restrict__ modes) {
+                                                     double *__restrict__ modes, size_t in_stride = 0,
+                                                     size_t out_stride = 0, size_t modes_stride = 0) {
+    Y += blockIdx.y * in_stride; res += blockIdx.y * out_stride; pred += blockIdx.y * out_stride;
+    modes += blockIdx.y * modes_stride;
     const int cols = W >> 2, rows = H >> 2;
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= rows * cols) return;
@@ -162,7 +167,10 @@ __global__ __launch_bounds__(256) void k_intra_luma4(const uint8_t *__restrict__
 __global__ __launch_bounds__(64) void k_intra_luma16(const uint8_t *__restrict__ Y, int H, int W,
                                                      double *__restrict__ res,
                                                      double *__restrict__ pred,
-                                                     double *__restrict__ modes) {
+                                                     double *__restrict__ modes, size_t in_stride = 0,
+                                                     size_t out_stride = 0, size_t modes_stride = 0) {
+    Y += blockIdx.y * in_stride; res += blockIdx.y * out_stride; pred += blockIdx.y * out_stride;
+    modes += blockIdx.y * modes_stride;
     const int cols = W >> 4;
     const int bi = blockIdx.x / cols, bj = blockIdx.x - bi * cols;
     const int i = bi * 16, j = bj * 16;
@@ -214,7 +222,12 @@ __global__ __launch_bounds__(64) void k_intra_chroma8(const uint8_t *__restrict_
                                                       double *__restrict__ crpred,
                                                       double *__restrict__ cbres,
                                                       double *__restrict__ cbpred,
-                                                      double *__restrict__ modes) {
+                                                      double *__restrict__ modes, size_t in_stride = 0,
+                                                      size_t out_stride = 0, size_t modes_stride = 0) {
+    Cr += blockIdx.y * in_stride; Cb += blockIdx.y * in_stride;
+    crres += blockIdx.y * out_stride; crpred += blockIdx.y * out_stride;
+    cbres += blockIdx.y * out_stride; cbpred += blockIdx.y * out_stride;
+    modes += blockIdx.y * modes_stride;
     __shared__ int s_ub[8];
     const int cols = W >> 3, rows = H >> 3;
     const int bj = blockIdx.x, j = bj * 8;
@@ -290,7 +303,9 @@ __global__ __launch_bounds__(64) void k_intra_chroma8(const uint8_t *__restrict_
 // 4x4 block, rows as 32-byte loads; products left to right, np.round = rint.
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_intra_transform4(const double *__restrict__ X, int H, int W,
-                                                          double *__restrict__ out) {
+                                                          double *__restrict__ out, size_t in_stride = 0,
+                                                          size_t out_stride = 0) {
+    X += blockIdx.y * in_stride; out += blockIdx.y * out_stride;
     const int nbx = W >> 2, nb = nbx * (H >> 2);
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;

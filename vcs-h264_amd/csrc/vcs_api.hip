@@ -100,6 +100,11 @@ struct vcs_ctx {
     uint32_t *d_ns = nullptr;
     void *d_planes = nullptr;
     double *d_intra = nullptr;  // intra prediction outputs: 4 planes + modes, float64
+    // vcs_intra_batch_*: n I frames resident -- per frame three uint8 planes in (ib_in) and, float64, the luma4
+    // pair, the luma16 pair, the four chroma planes, the transform of the luma4 residual and the three mode maps
+    uint8_t *ib_in = nullptr;
+    double *ib_out = nullptr;
+    int ib_frames = 0;
     double *d_DQ = nullptr;  // D[64] + Q[192] + 1/Q[192]
     double hDQ[448];
     bool fastdiv = false;    // Q table admits the 3-FMA exact division
@@ -977,6 +982,7 @@ int vcs_ctx_destroy(vcs_ctx *c) {
     if (c->s_side) hipStreamDestroy(c->s_side);
     hipFree(c->d_clk);
     hipFree(c->d_intra);
+    hipFree(c->ib_in); hipFree(c->ib_out);
     if (c->xev) hipEventDestroy(c->xev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1674,6 +1680,110 @@ int vcs_intra_transform4x4(vcs_ctx *c, const double *res, double *out) {
                        din, H, W, dout);
     if ((rc = t_end(c, &ev))) return rc;
     HIP_TRY(c, hipMemcpyAsync(out, dout, hw * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+// ---- intra prediction over a batch of I frames ----------------------------------------------
+// Layout of one frame's outputs in ib_out (float64 elements, hw = H * W): luma4 res, pred | luma16 res, pred |
+// chroma crres, crpred, cbres, cbpred | transform4(luma4 res) | modes: luma4 (hw/16), luma16 (hw/256), chroma (hw/64)
+namespace {
+struct IbLayout { size_t hw, m4, m16, m8, per_frame; };
+IbLayout ib_layout(const vcs_ctx *c) {
+    IbLayout l;
+    l.hw = (size_t)c->g.H * c->g.W;
+    l.m4 = l.hw / 16; l.m16 = l.hw / 256; l.m8 = l.hw / 64;
+    l.per_frame = 9 * l.hw + round_up(l.m4 + l.m16 + l.m8, 16);
+    return l;
+}
+}  // namespace
+
+int vcs_intra_batch_reserve(vcs_ctx *c, int n_frames) {
+    int rc = use(c);
+    if (rc) return rc;
+    if (n_frames < 1) return fail(c, VCS_E_ARG, "n_frames must be >= 1");
+    if (c->g.H % 16 || c->g.W % 16)
+        return fail(c, VCS_E_ARG, "the intra batch needs plane sizes that are multiples of 16 "
+                    "(the reference resizes to multiples of 16 first, intraframe.py:324)");
+    if (n_frames <= c->ib_frames) return VCS_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(c->ib_in); hipFree(c->ib_out);
+    c->ib_in = nullptr; c->ib_out = nullptr; c->ib_frames = 0;
+    const IbLayout l = ib_layout(c);
+    HIP_TRY(c, hipMalloc(&c->ib_in, (size_t)n_frames * 3 * l.hw + 256));
+    HIP_TRY(c, hipMalloc(&c->ib_out, (size_t)n_frames * l.per_frame * sizeof(double)));
+    c->ib_frames = n_frames;
+    return VCS_OK;
+}
+
+static int ib_range(vcs_ctx *c, int first, int n) {
+    if (!c->ib_in) return fail(c, VCS_E_STATE, "no intra batch reserved (vcs_intra_batch_reserve)");
+    if (first < 0 || n < 1 || first + n > c->ib_frames)
+        return fail(c, VCS_E_ARG, "frames [%d, %d) outside the %d reserved", first, first + n, c->ib_frames);
+    return VCS_OK;
+}
+
+int vcs_intra_batch_upload(vcs_ctx *c, int first, int n, const uint8_t *Y, const uint8_t *Cr, const uint8_t *Cb) {
+    int rc = use(c);
+    if (rc || (rc = ib_range(c, first, n))) return rc;
+    if (!Y || !Cr || !Cb) return fail(c, VCS_E_ARG, "null pointer");
+    const IbLayout l = ib_layout(c);
+    // per frame [Y][Cr][Cb]; the caller's arrays are n x H x W each
+    const uint8_t *src[3] = {Y, Cr, Cb};
+    for (int k = 0; k < 3; k++)
+        HIP_TRY(c, hipMemcpy2DAsync(c->ib_in + ((size_t)first * 3 + k) * l.hw, 3 * l.hw, src[k], l.hw, l.hw, (size_t)n,
+                                    hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VCS_OK;
+}
+
+int vcs_intra_batch_run(vcs_ctx *c, int first, int n, int what) {
+    int rc = use(c);
+    if (rc || (rc = ib_range(c, first, n))) return rc;
+    if (what < 1 || what > 15) return fail(c, VCS_E_ARG, "what = %d: a mask of 1 (luma 4x4), 2 (luma 16x16), 4 (chroma 8x8), 8 (4x4 transform)", what);
+    const IbLayout l = ib_layout(c);
+    const int H = c->g.H, W = c->g.W;
+    const uint8_t *in = c->ib_in + (size_t)first * 3 * l.hw;
+    double *out = c->ib_out + (size_t)first * l.per_frame, *modes = out + 9 * l.hw;
+    const size_t is = 3 * l.hw, os = l.per_frame;
+    EvPair ev;
+    if ((rc = t_begin(c, VCS_T_AUX, &ev))) return rc;
+    if (what & 1)
+        hipLaunchKernelGGL(k_intra_luma4, dim3((unsigned)((l.m4 + 255) / 256), n), dim3(256), 0, c->stream, in, H, W,
+                           out, out + l.hw, modes, is, os, os);
+    if (what & 2)
+        hipLaunchKernelGGL(k_intra_luma16, dim3((unsigned)l.m16, n), dim3(64), 0, c->stream, in, H, W, out + 2 * l.hw,
+                           out + 3 * l.hw, modes + l.m4, is, os, os);
+    if (what & 4)   // serial down each block column (intraframe.py:266), but the columns of ALL frames at once
+        hipLaunchKernelGGL(k_intra_chroma8, dim3(W / 8, n), dim3(64), 0, c->stream, in + l.hw, in + 2 * l.hw, H, W,
+                           out + 4 * l.hw, out + 5 * l.hw, out + 6 * l.hw, out + 7 * l.hw, modes + l.m4 + l.m16, is, os, os);
+    if (what & 8) {
+        if (!(what & 1)) return fail(c, VCS_E_ARG, "the 4x4 transform (8) runs on the luma 4x4 residual (1) of the same call");
+        hipLaunchKernelGGL(k_intra_transform4, dim3((unsigned)((l.m4 + 255) / 256), n), dim3(256), 0, c->stream, out, H, W,
+                           out + 8 * l.hw, os, os);
+    }
+    return t_end(c, &ev);
+}
+
+int vcs_intra_batch_get(vcs_ctx *c, int frame, int which, double *p0, double *p1, double *p2, double *p3, double *modes) {
+    int rc = use(c);
+    if (rc || (rc = ib_range(c, frame, 1))) return rc;
+    const IbLayout l = ib_layout(c);
+    const double *out = c->ib_out + (size_t)frame * l.per_frame, *m = out + 9 * l.hw;
+    const double *src[4] = {nullptr, nullptr, nullptr, nullptr};
+    const double *msrc = nullptr;
+    size_t mn = 0;
+    switch (which) {
+        case 0: src[0] = out; src[1] = out + l.hw; msrc = m; mn = l.m4; break;                                  // luma4: res, pred
+        case 1: src[0] = out + 2 * l.hw; src[1] = out + 3 * l.hw; msrc = m + l.m4; mn = l.m16; break;           // luma16
+        case 2: for (int k = 0; k < 4; k++) src[k] = out + (4 + k) * l.hw; msrc = m + l.m4 + l.m16; mn = l.m8; break;   // chroma
+        case 3: src[0] = out + 8 * l.hw; break;                                                                  // transform
+        default: return fail(c, VCS_E_ARG, "which = %d (0 luma 4x4, 1 luma 16x16, 2 chroma 8x8, 3 transform)", which);
+    }
+    double *dst[4] = {p0, p1, p2, p3};
+    for (int k = 0; k < 4; k++)
+        if (src[k] && dst[k]) HIP_TRY(c, hipMemcpyAsync(dst[k], src[k], l.hw * 8, hipMemcpyDeviceToHost, c->stream));
+    if (msrc && modes) HIP_TRY(c, hipMemcpyAsync(modes, msrc, mn * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return VCS_OK;
 }

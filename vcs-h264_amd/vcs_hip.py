@@ -97,6 +97,10 @@ SIGNATURES = {
     "vcs_intra_luma16x16": (ctypes.c_int, [_c_ctx, _u8p, _f64p, _f64p, _f64p]),
     "vcs_intra_chroma8x8": (ctypes.c_int, [_c_ctx, _u8p, _u8p, _f64p, _f64p, _f64p, _f64p, _f64p]),
     "vcs_intra_transform4x4": (ctypes.c_int, [_c_ctx, _f64p, _f64p]),
+    "vcs_intra_batch_reserve": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
+    "vcs_intra_batch_upload": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _u8p, _u8p, _u8p]),
+    "vcs_intra_batch_run": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "vcs_intra_batch_get": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _f64p, _f64p, _f64p, _f64p, _f64p]),
     "vcs_chroma420": (ctypes.c_int, [_c_ctx, _u8p, _u8p, _u8p, _u8p]),
     "vcs_stream_wait": (ctypes.c_int, [_c_ctx, _vp]),
     "vcs_stream_signal": (ctypes.c_int, [_c_ctx, _vp]),
@@ -498,6 +502,36 @@ class Context:
                                                *[o.ctypes.data_as(_f64p) for o in outs],
                                                modes.ctypes.data_as(_f64p)))
         return outs[0], outs[1], outs[2], outs[3], modes
+
+    # -- the same over a batch of I frames resident in HBM (vcs_intra_batch_*) --
+    INTRA_LUMA4, INTRA_LUMA16, INTRA_CHROMA8, INTRA_TRANSFORM4 = 1, 2, 4, 8
+
+    def intra_batch_reserve(self, n_frames):
+        self._ck(self._lib.vcs_intra_batch_reserve(self._h, int(n_frames)))
+
+    def intra_batch_upload(self, first, Y, Cr, Cb):
+        """Y, Cr, Cb: uint8 arrays of shape (n, H, W)."""
+        arrs = [np.ascontiguousarray(a, np.uint8) for a in (Y, Cr, Cb)]
+        n = arrs[0].shape[0]
+        for a in arrs:
+            if a.shape != (n, self.H, self.W):
+                raise ValueError("planes must be uint8 of shape (n, %d, %d)" % (self.H, self.W))
+        self._ck(self._lib.vcs_intra_batch_upload(self._h, int(first), n, *[a.ctypes.data_as(_u8p) for a in arrs]))
+
+    def intra_batch_run(self, first, n, what=15):
+        self._ck(self._lib.vcs_intra_batch_run(self._h, int(first), int(n), int(what)))
+
+    def intra_batch_get(self, frame, which):
+        """which 0 / 1: (res, pred, modes) of luma 4x4 / 16x16; 2: (crres, crpred, cbres, cbpred, modes) of chroma
+        8x8; 3: the 4x4 transform of the luma 4x4 residual."""
+        H, W = self.H, self.W
+        bs = {0: 4, 1: 16, 2: 8}.get(which)
+        planes = [np.zeros((H, W), np.float64) for _ in range({0: 2, 1: 2, 2: 4, 3: 1}[which])]
+        modes = np.zeros((H // bs, W // bs), np.float64) if bs else None
+        ptrs = [p.ctypes.data_as(_f64p) for p in planes] + [None] * (4 - len(planes))
+        self._ck(self._lib.vcs_intra_batch_get(self._h, int(frame), int(which), *ptrs,
+                                               modes.ctypes.data_as(_f64p) if bs else None))
+        return planes[0] if which == 3 else tuple(planes) + (modes,)
 
     def intra_transform4x4(self, res):
         """np.round(C . X . C^T) per 4x4 block of a float64 (H, W) plane (intraframe.py:352-358)."""
