@@ -282,6 +282,28 @@ def test_next_reference_tables_cut_beside_the_search(vh, oracle, bs):
             assert np.array_equal(mv[f], want) and ns[f] == wns, "late I frame, frame %d" % f
 
 
+def test_l3_prefetch_modes_change_nothing(vh, oracle):
+    """vcs_set_l3_prefetch: where the batch's frames are brought into the Infinity Cache for the tail (inside the
+    search launch, a separate pass, not at all) is scheduling only -- vectors and planes are the same."""
+    from synth import synth_gop
+    H, W, n = 144, 176, 7
+    ref, frames = synth_gop(H, W, n, seed=8)
+    want_mv = [oracle.me(frames[k], ref, 16)[0] for k in range(n)]
+    want_planes = oracle.encode_p(frames[n - 1], ref, 16)[1]
+    with vh.Context(H, W, 16) as c:
+        c.set_ref(ref)
+        c.gop_reserve(n)
+        c.gop_upload(0, frames)
+        for mode in (0, 1, 2, -1):
+            c.set_l3_prefetch(mode)
+            c.gop_encode(0, n)
+            mv, _ = c.gop_get_mv(0, n)
+            assert all(np.array_equal(mv[k], want_mv[k]) for k in range(n)), mode
+            assert np.array_equal(c.gop_get_planes(n - 1), want_planes), mode
+        with pytest.raises(vh.VcsError):
+            c.set_l3_prefetch(3)
+
+
 def test_pinned_host_buffers(vh, oracle):
     """vcs_host_alloc (frame feeder): frames produced into page-locked memory go
     through the same entry points with the same results; the memory is released with the array."""
