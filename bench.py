@@ -171,7 +171,7 @@ def host_path(H, W, bs, ref, frames, device, n_frames=48):
             # steady state: the better of two passes (a pass that has to grow the device heap for
             # its plane slabs pays tens of milliseconds once)
             per_frame, done = min(run(6, n_frames, False), run(6 + n_frames, n_frames, False))
-            per_frame_prod, _ = run(6 + 2 * n_frames, n_frames, True)
+            per_frame_prod, _ = min(run(6 + 2 * n_frames, n_frames, True), run(6 + 3 * n_frames, n_frames, True))
         N = (H // bs) * (W // bs)
         res[label] = {"encode_frame_ms": round(per_frame * 1e3, 4),
                       "with_producer_copy_ms": round(per_frame_prod * 1e3, 4),
@@ -881,7 +881,7 @@ def main():
             # pairs.  How close it is to that roof, priced with the clock the chip held in this run
             # (longest workgroup lifetime in shader cycles / launch duration).
             me_ms = ms[vcs_hip.T_ME] / max(1, int(launches[vcs_hip.T_ME]))
-            valu_per_mb = 486.0
+            valu_per_mb = None      # the PMC count belongs to a build: none for this one -> no fraction
             try:
                 kj = tj["kernels"]["k_me16b"]
                 valu_per_mb = round(kj["valu_wave_insts_per_dispatch"] / (tj["workload"]["frames_per_launch"] * N), 1)
@@ -893,11 +893,11 @@ def main():
 
             def frac(cycles_per_inst, t_ms):
                 return (round(valu_per_mb * cycles_per_inst * n0 * N / (1024 * clock_ghz * 1e9 * t_ms * 1e-3), 3)
-                        if clock_ghz else None)
+                        if clock_ghz and valu_per_mb else None)
             out["k_me16b_valu_issue"] = {
                 "clock_ghz_measured": round(clock_ghz, 3) if clock_ghz else None,
                 "valu_wave_insts_per_macroblock": valu_per_mb,
-                "valu_count_from": "profiles/hbm_traffic.json (PMC, this build)" if tj else "default (no PMC file for this build)",
+                "valu_count_from": "profiles/hbm_traffic.json (PMC, this build)" if valu_per_mb else "none: profiles/hbm_traffic.json is of another build",
                 "of_which_comparison_core": core,
                 "launch_ms": round(me_ms, 4),
                 "search_alone_ms": round(alone, 4) if me_alone_ms else None,
