@@ -255,3 +255,36 @@ def test_intramodes_dropin_matches_the_reference_functions():
             for k in range(len(u)):
                 got = getattr(im, name)(*a(k))
                 assert got.dtype == np.float64 and np.array_equal(got, want[k]), (name, k)
+
+
+def test_smem_pipeline_checker_on_synthetic_assembly(tmp_path):
+    """tools/check_smem_pipeline.py (part of the library's build): a copy of a register whose hand-issued scalar
+    load is still in flight is found along every path of the control-flow graph -- also around a loop's back
+    edge and past a block that only sits between the two in the text --, a wait clears the set, and a kernel
+    without hand-issued loads is an error (the check would be vacuous)."""
+    import subprocess
+    import sys
+    tool = os.path.join(REPO, "tools", "check_smem_pipeline.py")
+    head = "_ZN3vcs7k_demoEv:\n"
+    issue = "\t;;#ASMSTART\n\ts_load_dwordx8 s[8:15], s[2:3], s4\n\t;;#ASMEND\n"
+    wait = "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n"
+    tail = "\ts_endpgm\n.Lfunc_end0:\n"
+    cases = {
+        # straight line: request, wait, use
+        "ok": head + issue + "\ts_add_u32 s20, s21, s22\n" + wait + "\tv_mov_b32_e32 v0, s8\n" + tail,
+        # a copy of the in-flight tuple before the wait
+        "copy": head + issue + "\ts_mov_b64 s[30:31], s[8:9]\n" + wait + tail,
+        # in flight around a loop's back edge: the use at the loop's head comes before the wait
+        "loop": head + issue + ".LBB0_1:\n\tv_mov_b32_e32 v1, s9\n" + wait + issue + "\ts_cbranch_scc1 .LBB0_1\n" + wait + tail,
+        # a block that is skipped over (s_branch) while the load is in flight may use the registers' numbers
+        # for nothing: it is not reachable with them in flight
+        "skipped": head + "\ts_cbranch_scc1 .LBB0_2\n" + issue + "\ts_branch .LBB0_3\n.LBB0_2:\n\ts_mov_b32 s8, 0\n"
+                   "\ts_branch .LBB0_4\n.LBB0_3:\n" + wait + ".LBB0_4:\n" + tail,
+        "none": head + "\ts_nop 0\n" + tail,
+    }
+    want = {"ok": 0, "copy": 1, "loop": 1, "skipped": 0, "none": 1}
+    for name, text in cases.items():
+        f = tmp_path / (name + ".s")
+        f.write_text(text)
+        r = subprocess.run([sys.executable, tool, str(f), "k_demo"], capture_output=True, text=True)
+        assert r.returncode == want[name], (name, r.stdout, r.stderr)

@@ -45,17 +45,20 @@ def parse(lines, start, end):
         rest = rest.split(";")[0]
         toks = [t.strip() for t in re.split(r",\s*(?![^\[]*\])", rest) if t.strip()]
         b = blocks[-1]
-        if not b["fall"]:       # code behind an unconditional branch without a label: its own (unreachable) block
+        if b.get("closed"):     # code behind a branch without a label of its own: a new block
             blocks.append({"label": "anon%d" % i, "insts": [], "succ": [], "fall": True})
             b = blocks[-1]
         b["insts"].append((i + 1, op, toks, in_asm))
         if op == "s_branch":
             b["succ"].append(toks[0])
             b["fall"] = False
-        elif op.startswith("s_cbranch"):
+            b["closed"] = True
+        elif op.startswith("s_cbranch"):    # ends the block: the target and the fall-through both follow
             b["succ"].append(toks[-1])
+            b["closed"] = True
         elif op == "s_endpgm":
             b["fall"] = False
+            b["closed"] = True
     return blocks
 
 
