@@ -503,12 +503,6 @@ __device__ __forceinline__ BitsTask bits_task(int j, int lane, int n2, uint32_t 
     return k;
 }
 
-// (tuning builds: -DVCS_BITS_PRIO=abcd -- wave priority in the prologue / first pass / second pass / end, one digit each)
-#ifdef VCS_BITS_PRIO
-#define BITS_PRIO(i) __builtin_amdgcn_s_setprio((VCS_BITS_PRIO / (i == 0 ? 1000 : i == 1 ? 100 : i == 2 ? 10 : 1)) % 10)
-#else
-#define BITS_PRIO(i) do { } while (0)
-#endif
 #ifdef VCS_EXP_PHASES   // experiment builds only (tools/gpu_phases_bits.py): where a search wave's time goes
 __device__ unsigned long long g_me16b_phases[8];   // [0..4]: shader cycles in prologue / first pass / between / second pass / end; [5]: waves sampled
 #define BITS_PROBE(i) do { if (probing) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] = t_; } } while (0)
@@ -589,7 +583,6 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
 #endif
     BITS_PROBE(0);
-    BITS_PRIO(0);
     if (bits_unit(ul, A_, xcd, u)) {
         // A wave's first loads -- the static-test records, the first chunk, the planes of the first two
         // row pairs -- are all requested before the first of them is waited for: one round trip at the
@@ -650,7 +643,6 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
         if (!searching)   // nothing may be in flight when the wave ends (the LDS-direct loads write LDS)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BITS_PROBE(1);
-        BITS_PRIO(1);
         if (searching) {
             // ---- first pass: planes of the block in SGPRs ----------------------------------------
             uint32_t acc[NF];
@@ -710,7 +702,6 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
             for (int f = 0; f < NF; f++) best[f] = base + (acc[f] << 15);
         }
         BITS_PROBE(2);
-        BITS_PRIO(2);
         // everything is loaded and derived again from here on (see BitsArgs)
         asm volatile("" : "+s"(ul));
         const BitsArgs B_ = bits_args_fetch(bits_args_again());
@@ -765,7 +756,6 @@ __global__ __launch_bounds__(64 * kBitsWpw) void k_me16b(BitsArgs args_by_value)
             }
             wave_lds_fence();
             BITS_PROBE(4);
-            BITS_PRIO(3);
             if (lane < n2) {
                 const uint32_t base2 = (B->sums[(size_t)u.blk * kMe16SumStride + 64 + lane] << 7) | (uint32_t)(64 + lane);
 #pragma unroll
