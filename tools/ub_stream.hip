@@ -79,7 +79,79 @@ static float run_dec(const double *pl[3], uint8_t *img, int H, int W, int n) {
     return best;
 }
 
+// write-pattern variants of the k_fdct shape (no reads at all): which row-run geometry does HBM like best?
+//  RUN = bytes one store instruction writes contiguously (512: two rows per instruction as k_fdct does; 1024: one row of
+//  128 columns), WAVES per workgroup side by side in x.
+template <int RUN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_wshape(double *planes, int H, int W, int n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t plane = (size_t)H * W;
+    double *out = planes + (size_t)blockIdx.y * 3 * plane;
+    d2 v; v.x = 1.0 + lane; v.y = 2.0;
+    if (RUN == 512) {   // strip = 64 columns x 8 rows
+        const int groups_x = W / 64, per_frame = groups_x * (H / 8);
+        const int s = min((int)blockIdx.x * WAVES + wave, per_frame - 1), ty = s / groups_x, gx = s - ty * groups_x;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                const int e = s4 * 64 + lane, row = e >> 5, c2 = e & 31;
+                __builtin_nontemporal_store(v, (d2 *)(out + ch * plane + (size_t)(ty * 8 + row) * W + gx * 64 + 2 * c2));
+            }
+    } else {            // strip = 128 columns x 4 rows: one row per instruction
+        const int groups_x = W / 128, per_frame = groups_x * (H / 4);
+        const int s = min((int)blockIdx.x * WAVES + wave, per_frame - 1), ty = s / groups_x, gx = s - ty * groups_x;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+            for (int row = 0; row < 4; row++)
+                __builtin_nontemporal_store(v, (d2 *)(out + ch * plane + (size_t)(ty * 4 + row) * W + gx * 128 + 2 * lane));
+    }
+}
+__global__ __launch_bounds__(256) void k_wlinear(d2 *p, size_t n2) {
+    d2 v; v.x = 1.0; v.y = 2.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(v, p + i);
+}
+template <int RUN, int WAVES>
+static float run_w(double *pl[3], int H, int W, int n) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9f;
+    const unsigned per_frame = RUN == 512 ? (unsigned)((W / 64) * (H / 8)) : (unsigned)((W / 128) * (H / 4));
+    for (int it = 0; it < 12; it++) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k_wshape<RUN, WAVES>), dim3((per_frame + WAVES - 1) / WAVES, n), dim3(64 * WAVES), 0, 0, pl[it % 3], H, W, n);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        if (it > 2 && ms < best) best = ms;
+    }
+    return best;
+}
+
 int main() {
+    {
+        const int H = 1080, W = 1920, n = 29;
+        const size_t F = (size_t)H * W * 3;
+        double *p0, *p1, *p2;
+        hipMalloc(&p0, F * n * 8); hipMalloc(&p1, F * n * 8); hipMalloc(&p2, F * n * 8);
+        double *pl[3] = {p0, p1, p2};
+        const double bytes = (double)F * n * 8;
+        float ms;
+#define WRUN(R, Wv) ms = run_w<R, Wv>(pl, H, W, n); printf("write shape, %4d-byte runs, %2d waves per workgroup: %.3f ms  %.0f GB/s\n", R, Wv, ms, bytes / ms / 1e6);
+        WRUN(512, 1) WRUN(512, 4) WRUN(512, 8) WRUN(512, 15) WRUN(1024, 1) WRUN(1024, 5) WRUN(1024, 15)
+        {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            float best = 1e9f;
+            for (int it = 0; it < 10; it++) {
+                hipEventRecord(a);
+                hipLaunchKernelGGL(k_wlinear, dim3(8192), dim3(256), 0, 0, (d2 *)pl[it % 3], (size_t)(F * n / 2));
+                hipEventRecord(b); hipEventSynchronize(b);
+                float t; hipEventElapsedTime(&t, a, b);
+                if (it > 2 && t < best) best = t;
+            }
+            printf("write linear (grid-stride, 16 bytes per lane):            %.3f ms  %.0f GB/s\n", best, bytes / best / 1e6);
+        }
+        hipFree(p0); hipFree(p1); hipFree(p2);
+    }
     {
         const int H = 1080, W = 1920, n = 29;
         const size_t F = (size_t)H * W * 3;
