@@ -886,7 +886,10 @@ inline int me_bits_mode() {
 // 1.82; n = 29: 2.75 vs 3.55.  (The table in four bands of 60 block columns, each rebuilt per launch:
 // n = 29 2.86 ms -- more launches, nothing gained from the smaller table; with the SEARCH in sub-batches
 // of 8 frames, each re-reading the table: 3.8 ms.)
-constexpr int kBitsMinFrames = 6, kBitsMinFramesBig = 10;
+// Round 4 (the restructured k_me16b; tools/exp sizes run, k macroblocks/ms, bit-plane vs k_me16g): 1080p n = 3: 135 vs 151;
+// n = 4: 163 vs 164; n = 5: 187 vs 171; n = 6: 206 vs 177; n = 8: 235 vs 186.  4K n = 4: 166 vs 231; n = 6: 200 vs 228;
+// n = 8: 226 vs 273; n = 10: 282 vs 251; n = 12: 301 vs 266.
+constexpr int kBitsMinFrames = 5, kBitsMinFramesBig = 10;
 inline bool me_bits_worthwhile(const Geom &g, int n) {
     const int m = me_bits_mode();
     if (m == 0 || !me_fast_supported(g)) return false;
