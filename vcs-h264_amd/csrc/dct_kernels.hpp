@@ -464,16 +464,38 @@ __global__ __launch_bounds__(64 * kIdctWaves) IDCT_WPE void k_idct(
         b[3 * jj + 2] = (uint8_t)(R + (int)((p >> 16) & 255));
     }
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    // tiles past the right edge (W not a multiple of 64): an offset beyond the frame, dropped by the
-    // buffer's range check -- no branch (see above)
     const __amdgpu_buffer_rsrc_t r_out = buf_rsrc(outs + (size_t)f * out_stride, (uint32_t)(g.H * g.pitch));
-    const uint32_t oo = gx * 64 + t * 8 < g.W ? (uint32_t)(y * g.pitch + 3 * xo) : 0xFFFFFF00u;
+    u32x2 v[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-        u32x2 v;
-        v.x = b[8 * q] | (b[8 * q + 1] << 8) | (b[8 * q + 2] << 16) | ((uint32_t)b[8 * q + 3] << 24);
-        v.y = b[8 * q + 4] | (b[8 * q + 5] << 8) | (b[8 * q + 6] << 16) | ((uint32_t)b[8 * q + 7] << 24);
-        __builtin_amdgcn_raw_buffer_store_b64(v, r_out, (int)(oo + 8u * q), 0, kBufNt);
+        v[q].x = b[8 * q] | (b[8 * q + 1] << 8) | (b[8 * q + 2] << 16) | ((uint32_t)b[8 * q + 3] << 24);
+        v[q].y = b[8 * q + 4] | (b[8 * q + 5] << 8) | (b[8 * q + 6] << 16) | ((uint32_t)b[8 * q + 7] << 24);
+    }
+    if (gx * 64 + 64 <= g.W) {   // (uniform) a whole strip: its 8 rows x 192 bytes leave as 16-byte pieces, 12 in a row
+        // Round 3 stored a lane's 24 bytes as three 8-byte pieces: one store instruction wrote 8 of every 24 bytes
+        // of a row, the next the following 8 -- WRITE_SIZE 294 MB for 180 MB of frames.  Through LDS (s_t is
+        // free: every lane has its row of T in registers) a row's 192 bytes are written by 12 adjacent lanes.
+        uint8_t *s_b = (uint8_t *)s_t;
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < 3; q++) *(u32x2 *)(s_b + j * 192 + t * 24 + 8 * q) = v[q];
+        wave_lds_fence();
+        const uint32_t row0 = (uint32_t)(ty * 8) * (uint32_t)g.pitch + (uint32_t)gx * 192u;
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int e = lane + 64 * it;
+            if (e < 96) {
+                const int row = e / 12, piece = e - row * 12;
+                const u32x4_t w = *(const u32x4_t *)(s_b + row * 192 + piece * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(w, r_out, (int)(row0 + (uint32_t)row * (uint32_t)g.pitch + 16u * (uint32_t)piece), 0, kBufNt);
+            }
+        }
+    } else {
+        // a strip that crosses the right edge (W not a multiple of 64): tiles past the edge get an offset beyond the
+        // frame, dropped by the buffer's range check
+        const uint32_t oo = gx * 64 + t * 8 < g.W ? (uint32_t)(y * g.pitch + 3 * xo) : 0xFFFFFF00u;
+#pragma unroll
+        for (int q = 0; q < 3; q++) __builtin_amdgcn_raw_buffer_store_b64(v[q], r_out, (int)(oo + 8u * q), 0, kBufNt);
     }
 }
 
